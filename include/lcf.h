@@ -1,0 +1,160 @@
+/*
+ * lcf.h -- C ABI of liblcf.so: the MI355X (gfx950) native sparse front end of the SECOND
+ * detector (voxelize -> VFE -> sparse 3D middle extractor) as used by
+ * CMU-Light-Curtains/ObjectDetection.
+ *
+ * Conventions
+ *   - Every pointer is a DEVICE pointer unless the comment says "host".
+ *   - The caller (PyTorch host side) owns every buffer: inputs, outputs, workspaces.  No entry
+ *     point allocates or frees device memory, none synchronises the device; all work is
+ *     enqueued on `stream` (a hipStream_t passed as void*; NULL = the legacy default stream).
+ *   - Return 0 on success, a negative LCF_ERR_* otherwise; lcf_strerror() names it.
+ *   - Data-dependent sizes (number of voxels, number of active outputs) come back through
+ *     device int32 scalars; the caller passes capacities.
+ *
+ * The reference binds this path through the third-party `spconv` python package (1.x, not
+ * vendored, README.md:29) and a numba kernel; each entry point below names the reference
+ * interface / call site it replaces (paths relative to the reference repo root).
+ */
+#ifndef LCF_H_
+#define LCF_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LCF_OK 0
+#define LCF_ERR_ARG (-1)         /* bad argument (null pointer, non-positive size, ...) */
+#define LCF_ERR_WORKSPACE (-2)   /* workspace too small */
+#define LCF_ERR_UNSUPPORTED (-3) /* shape outside what the kernels are built for */
+#define LCF_ERR_RANGE (-4)       /* grid too large for 32-bit cell keys */
+#define LCF_ERR_LAUNCH (-5)      /* HIP reported a launch error */
+
+#define LCF_MAX_KVOL 64 /* kernel volume limit of the rulebook / conv kernels (3x3x3 = 27) */
+
+const char *lcf_strerror(int rc);
+int lcf_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Voxelization.
+ * Replaces: spconv.utils.VoxelGeneratorV2.generate / generate_multi_gpu
+ *           (second/builder/voxel_builder.py:23-33, second/data/preprocess.py:626-639) and
+ *           second.core.point_cloud.point_cloud_ops.points_to_voxel
+ *           (second/kittiviewer/viewer.py:389-396; loop shape second/utils/simplevis.py:23-50).
+ *
+ * points [n,f] f32 row-major (x,y,z,...).  Outputs (capacity max_vox rows, every row written:
+ * rows >= *voxel_num are zero): voxels [max_vox,max_pts,f] f32, coors [max_vox,3] i32 (z,y,x),
+ * num_pts [max_vox] i32, voxel_num [1] i32.  Results are bit-identical to the sequential
+ * first-come loop: voxel ids in order of first appearance, the first max_pts points (by index)
+ * kept per voxel.  cap_mode 0 = `break` when a new voxel would exceed max_vox (numba twin),
+ * 1 = `continue` (spconv C++ behaviour).  vs / range are HOST arrays.
+ */
+size_t lcf_voxelize_workspace_bytes(int n, int max_pts);
+int lcf_voxelize(const float *points, int n, int f, const float vs[3], const float range[6],
+                 int max_pts, int max_vox, int cap_mode, float *voxels, int *coors,
+                 int *num_pts, int *voxel_num, void *ws, size_t ws_bytes, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Rulebooks (spconv.ops.get_indice_pairs as called by SparseConvolution.forward for
+ * second/pytorch/models/middle.py:145-192).
+ *
+ * The native rulebook is a pair of NEIGHBOUR TABLES instead of spconv's compacted pair lists:
+ *   out_nbr [k_out,kvol] i32: input row feeding output row n through kernel offset o, or -1
+ *   in_nbr  [k_in ,kvol] i32: output row fed by input row j through kernel offset o, or -1
+ * (kernel offset o = kz*KH*KW + ky*KW + kx, k_d = in_d - out_d*stride_d + pad_d).
+ * lcf_rulebook_pairs() converts in_nbr into spconv's canonical indice_pairs [2,kvol,k_in] /
+ * indice_pair_num [kvol] (pairs of one offset in ascending input row order, -1 padded),
+ * bit-identical to spconv's CPU get_indice_pairs.
+ *
+ * coors [k,4] i32 (b,z,y,x).  shape/ksize/stride/pad/dil are HOST int[3] (z,y,x order).
+ */
+size_t lcf_rulebook_subm_workspace_bytes(int k);
+int lcf_rulebook_subm(const int *coors, int k, int batch, const int shape[3],
+                      const int ksize[3], const int dil[3], int *out_nbr, void *ws,
+                      size_t ws_bytes, void *stream);
+
+/* Strided / ordinary sparse conv, two phases (the caller reads *k_out between them to size
+ * the tables, exactly as spconv synchronises to size its output):
+ *   discover: out_coors [cap_out,4] in CPU-discovery (canonical) order, *k_out (device i32);
+ *             cap_out >= lcf_rulebook_conv_max_out(k_in, ksize, stride).
+ *   fill:     out_nbr [k_out,kvol], in_nbr [k_in,kvol]; needs the SAME ws untouched in between.
+ */
+int lcf_rulebook_conv_max_out(int k_in, const int ksize[3], const int stride[3]);
+void lcf_conv_out_shape(const int shape[3], const int ksize[3], const int stride[3],
+                        const int pad[3], const int dil[3], int out_shape[3]);
+size_t lcf_rulebook_conv_workspace_bytes(int k_in, const int ksize[3], const int stride[3]);
+int lcf_rulebook_conv_discover(const int *coors, int k_in, int batch, const int shape[3],
+                               const int ksize[3], const int stride[3], const int pad[3],
+                               const int dil[3], int *out_coors, int cap_out, int *k_out,
+                               void *ws, size_t ws_bytes, void *stream);
+int lcf_rulebook_conv_fill(const int *coors, int k_in, int batch, const int shape[3],
+                           const int ksize[3], const int stride[3], const int pad[3],
+                           const int dil[3], int k_out, int *out_nbr, int *in_nbr, void *ws,
+                           size_t ws_bytes, void *stream);
+
+/* mirror a submanifold table: in_nbr[j][o] = out_nbr[j][kvol-1-o] */
+int lcf_rulebook_mirror(const int *nbr, int k, int kvol, int *mirrored, void *stream);
+
+size_t lcf_rulebook_pairs_workspace_bytes(int k_in, int kvol);
+int lcf_rulebook_pairs(const int *in_nbr, int k_in, int kvol, int *pairs, int *pair_num,
+                       void *ws, size_t ws_bytes, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * indice_conv (torch.ops.spconv.indice_conv / indice_conv_backward as used by
+ * spconv.SparseConv3d / SubMConv3d in second/pytorch/models/middle.py:127-192).
+ *
+ * Weights arrive in the reference layout [kD,kH,kW,Cin,Cout] = [kvol,Cin,Cout] f32 and are
+ * first re-laid into an MFMA "weight image" (lcf_weight_image; transpose=1 builds the image of
+ * W[o]^T for dgrad).  Image size: lcf_weight_image_elems(kvol,cin,cout) floats.
+ *
+ * fwd : out[n,:] = act( (sum_o feat[out_nbr[n][o],:] @ W[o]) * scale + shift ), offsets
+ *       ascending, fp32 FMA accumulation on the fp32 MFMA pipe.  scale/shift [cout] may be
+ *       NULL (identity; shift alone = bias); relu != 0 applies max(x,0).  This one kernel is
+ *       the fused gather-GEMM-scatter: the scatter is the row's own store.
+ * dgrad = the same entry point with in_nbr and the transposed image.
+ * wgrad: dw[o] (+)= feat[j,:]^T dout[in_nbr[j][o],:]  -> dw [kvol,cin,cout] f32 (zeroed inside).
+ */
+size_t lcf_weight_image_elems(int kvol, int cin, int cout, int transpose);
+int lcf_weight_image(const float *w, int kvol, int cin, int cout, int transpose, float *img,
+                     void *stream);
+int lcf_indice_conv_fwd(const float *feat, const float *wimg, const int *nbr, int k_out,
+                        int kvol, int cin, int cout, const float *scale, const float *shift,
+                        int relu, float *out, void *stream);
+int lcf_indice_conv_wgrad(const float *feat, const float *dout, const int *in_nbr, int k_in,
+                          int kvol, int cin, int cout, float *dw, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * SparseConvTensor.dense() (second/pytorch/models/middle.py:206): out [B,C,D,H,W] f32 is
+ * zero-filled and scattered from feat [k,c], coors [k,4].  dense_bwd gathers it back.
+ */
+int lcf_dense(const float *feat, const int *coors, int k, int c, int batch, const int shape[3],
+              float *out, void *stream);
+int lcf_dense_bwd(const float *dout, const int *coors, int k, int c, int batch,
+                  const int shape[3], float *dfeat, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * VFE streaming kernels (second/pytorch/models/voxel_encoder.py).
+ * vfe_mean : SimpleVoxel.forward (:220-225): out[k,:c] = sum_t voxels[k,t,:c] / num[k].
+ * vfe_augment: VoxelFeatureExtractor.forward :116-124: out[k,t,:] = concat(voxels[k,t,:f],
+ *            voxels[k,t,:3] - mean_t) ([k,t,f+3]).
+ * vfe_pool : the tail of VFELayer.forward (:69-80) and of VoxelFeatureExtractor.forward
+ *            (:134-139) after the Linear: y = relu(x*scale + shift) per channel (BatchNorm in
+ *            affine form), then
+ *              mode 0: out [k,t,2u] = concat(y, max_t y) * mask[k,t]      (VFELayer + mask)
+ *              mode 1: out [k,u]    = max_t (y * mask[k,t])               (final max-pool)
+ *            with mask[k,t] = t < num[k]  (get_paddings_indicator :27-48).
+ */
+int lcf_vfe_mean(const float *voxels, const int *num, int k, int t, int f, int c, float *out,
+                 void *stream);
+int lcf_vfe_augment(const float *voxels, const int *num, int k, int t, int f, float *out,
+                    void *stream);
+int lcf_vfe_pool(const float *x, const int *num, int k, int t, int u, const float *scale,
+                 const float *shift, int mode, float *out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LCF_H_ */

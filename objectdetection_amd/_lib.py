@@ -1,0 +1,105 @@
+"""ctypes binding of liblcf.so (include/lcf.h).  Fails loudly when the library is missing:
+there is no CPU fallback in the product path."""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblcf.so")
+
+c_int = ctypes.c_int
+c_size_t = ctypes.c_size_t
+c_void_p = ctypes.c_void_p
+_I3 = ctypes.c_int * 3
+_F3 = ctypes.c_float * 3
+_F6 = ctypes.c_float * 6
+
+# every symbol include/lcf.h declares: (restype, argtypes)
+_PI3 = ctypes.POINTER(ctypes.c_int)
+_PF = ctypes.POINTER(ctypes.c_float)
+SYMBOLS = {
+    "lcf_strerror": (ctypes.c_char_p, [c_int]),
+    "lcf_version": (c_int, []),
+    "lcf_voxelize_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "lcf_voxelize": (c_int, [c_void_p, c_int, c_int, _PF, _PF, c_int, c_int, c_int, c_void_p,
+                             c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "lcf_rulebook_subm_workspace_bytes": (c_size_t, [c_int]),
+    "lcf_rulebook_subm": (c_int, [c_void_p, c_int, c_int, _PI3, _PI3, _PI3, c_void_p, c_void_p,
+                                  c_size_t, c_void_p]),
+    "lcf_rulebook_conv_max_out": (c_int, [c_int, _PI3, _PI3]),
+    "lcf_conv_out_shape": (None, [_PI3, _PI3, _PI3, _PI3, _PI3, _PI3]),
+    "lcf_rulebook_conv_workspace_bytes": (c_size_t, [c_int, _PI3, _PI3]),
+    "lcf_rulebook_conv_discover": (c_int, [c_void_p, c_int, c_int, _PI3, _PI3, _PI3, _PI3, _PI3,
+                                           c_void_p, c_int, c_void_p, c_void_p, c_size_t,
+                                           c_void_p]),
+    "lcf_rulebook_conv_fill": (c_int, [c_void_p, c_int, c_int, _PI3, _PI3, _PI3, _PI3, _PI3,
+                                       c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "lcf_rulebook_mirror": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "lcf_rulebook_pairs_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "lcf_rulebook_pairs": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                   c_size_t, c_void_p]),
+    "lcf_weight_image_elems": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "lcf_weight_image": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "lcf_indice_conv_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                    c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "lcf_indice_conv_wgrad": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                      c_void_p, c_void_p]),
+    "lcf_dense": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, _PI3, c_void_p, c_void_p]),
+    "lcf_dense_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, _PI3, c_void_p,
+                              c_void_p]),
+    "lcf_vfe_mean": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
+                             c_void_p]),
+    "lcf_vfe_augment": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "lcf_vfe_pool": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int,
+                             c_void_p, c_void_p]),
+}
+
+_lib = None
+
+
+def build(force=False):
+    """Compile liblcf.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+    if force:
+        subprocess.check_call(["make", "-s", "-C", os.path.join(_HERE, "csrc"), "clean"])
+    subprocess.check_call(["make", "-s", "-j4", "-C", os.path.join(_HERE, "csrc")])
+
+
+def lib():
+    """The loaded library; raises if liblcf.so has not been built (no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: build it with "
+                "`python -c 'import __graft_entry__ as g; g.build()'` or "
+                "`make -C objectdetection_amd/csrc`.  There is no CPU fallback.")
+        l = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(l, name)  # AttributeError if the ABI is incomplete
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise RuntimeError(lib().lcf_strerror(rc).decode())
+
+
+def i3(v):
+    """int | sequence of 3 -> ctypes int[3]."""
+    if isinstance(v, int):
+        v = (v, v, v)
+    v = [int(x) for x in v]
+    if len(v) != 3:
+        raise ValueError(f"expected 3 values, got {v}")
+    return _I3(*v)
+
+
+def f3(v):
+    return _F3(*[float(x) for x in v])
+
+
+def f6(v):
+    return _F6(*[float(x) for x in v])

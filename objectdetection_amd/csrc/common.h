@@ -1,0 +1,85 @@
+// common.h -- shared device helpers for liblcf (gfx950 only: wave64 hard-coded).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/lcf.h"
+
+#define LCF_WAVE 64
+#define LCF_EMPTY_KEY 0xFFFFFFFFu
+
+#define LCF_CHECK_LAUNCH()                                   \
+    do {                                                     \
+        if (hipGetLastError() != hipSuccess) return LCF_ERR_LAUNCH; \
+    } while (0)
+
+static inline size_t lcf_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+static inline uint32_t lcf_pow2_ge(uint32_t x)
+{
+    uint32_t p = 1;
+    while (p < x) p <<= 1;
+    return p;
+}
+
+// 32-bit integer hash (murmur3 finaliser)
+__device__ __forceinline__ uint32_t lcf_hash32(uint32_t h)
+{
+    h ^= h >> 16;
+    h *= 0x85ebca6bu;
+    h ^= h >> 13;
+    h *= 0xc2b2ae35u;
+    h ^= h >> 16;
+    return h;
+}
+
+// Insert `key` into an open-addressing table of `mask+1` slots (keys initialised to
+// LCF_EMPTY_KEY); returns the slot.  Concurrent inserts of equal keys return the same slot.
+__device__ __forceinline__ uint32_t lcf_hash_insert(uint32_t *keys, uint32_t mask, uint32_t key)
+{
+    uint32_t h = lcf_hash32(key) & mask;
+    while (true) {
+        uint32_t old = atomicCAS(&keys[h], LCF_EMPTY_KEY, key);
+        if (old == LCF_EMPTY_KEY || old == key) return h;
+        h = (h + 1) & mask;
+    }
+}
+
+// Find `key`; returns slot or 0xFFFFFFFF when absent.  Table must not be full.
+__device__ __forceinline__ uint32_t lcf_hash_find(const uint32_t *keys, uint32_t mask,
+                                                  uint32_t key)
+{
+    uint32_t h = lcf_hash32(key) & mask;
+    while (true) {
+        uint32_t cur = keys[h];
+        if (cur == key) return h;
+        if (cur == LCF_EMPTY_KEY) return 0xFFFFFFFFu;
+        h = (h + 1) & mask;
+    }
+}
+
+// Exclusive scan of one int per thread across a 256-thread block (4 waves).
+// `lds` must hold >= 5 ints.  Returns the exclusive prefix; *total = block sum.
+__device__ __forceinline__ int lcf_block_excl_scan_256(int v, int *lds, int *total)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    int incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        int t = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += t;
+    }
+    if (lane == 63) lds[wave] = incl;
+    __syncthreads();
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        int s = lds[w];
+        if (w < wave) base += s;
+        tot += s;
+    }
+    __syncthreads();
+    *total = tot;
+    return base + incl - v;
+}

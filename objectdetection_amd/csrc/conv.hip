@@ -1,0 +1,459 @@
+// conv.hip -- indice_conv forward / dgrad / wgrad on the gfx950 fp32 MFMA pipe.
+//
+// Replaces torch.ops.spconv.indice_conv(+_backward) as used by spconv.SparseConv3d/SubMConv3d
+// in second/pytorch/models/middle.py:127-192 (per-offset gather -> mm -> scatter-add).
+//
+// Forward is OUTPUT-STATIONARY over the neighbour table: a 16-row output tile per wave keeps its
+// accumulators in registers while it walks the kernel offsets; per offset it gathers the 16
+// input rows named by out_nbr (zeros where -1) straight into the MFMA A operand and multiplies
+// by W[o], which the workgroup stages through LDS (double buffered, one barrier per offset) in
+// an image laid out so every B fragment read is one conflict-free ds_read_b128.  The "scatter"
+// is the tile's own store, so there are no atomics and the result is run-to-run deterministic.
+// v_mfma_f32_16x16x4_f32 is an exact fp32 FMA chain (MI355X guide section 3), so results agree
+// with the CPU oracle to fp32 summation-order differences (<= 1e-4 relative is the test bar).
+#include "common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define CV_ROWS_PER_WAVE 16
+#define CV_WAVES 4
+#define CV_ROWS (CV_ROWS_PER_WAVE * CV_WAVES)
+#define CV_BLOCK (CV_WAVES * 64)
+
+static int cv_pad_cin(int c)
+{
+    const int s[] = {4, 8, 16, 32, 64, 128};
+    for (int i = 0; i < 6; ++i)
+        if (c <= s[i]) return s[i];
+    return -1;
+}
+static int cv_pad_cout(int c)
+{
+    const int s[] = {16, 32, 64, 128};
+    for (int i = 0; i < 4; ++i)
+        if (c <= s[i]) return s[i];
+    return -1;
+}
+
+// position (in floats) of W[k][c] inside one offset's image
+__host__ __device__ __forceinline__ int cv_img_pos(int k, int c, int CIN, int COUT)
+{
+    (void)COUT;
+    const int KL = CIN / 4;
+    const int VW = KL < 4 ? KL : 4;
+    const int SG = KL / VW;
+    int q = k / KL, s = k % KL;
+    int sg = s / VW, v = s % VW;
+    int t = c / 16, jj = c % 16;
+    return ((((t * SG + sg) * 4 + q) * 16 + jj) * VW) + v;
+}
+
+__global__ void __launch_bounds__(256)
+cv_weight_image_kernel(const float *__restrict__ w, int kvol, int cin, int cout, int CIN,
+                       int COUT, int transpose, float *__restrict__ img)
+{
+    // image element index e -> (o, k, c) of the (possibly transposed) padded matrix
+    long long total = (long long)kvol * CIN * COUT;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+         e += (long long)gridDim.x * blockDim.x) {
+        int o = (int)(e / (CIN * COUT));
+        int r = (int)(e - (long long)o * CIN * COUT);
+        int k = r / COUT, c = r % COUT;
+        float v = 0.f;
+        if (!transpose) {
+            if (k < cin && c < cout) v = w[((size_t)o * cin + k) * cout + c];
+        } else {
+            // image of W[o]^T : rows = original cout (k), cols = original cin (c)
+            if (k < cout && c < cin) v = w[((size_t)o * cin + c) * cout + k];
+        }
+        img[(size_t)o * CIN * COUT + cv_img_pos(k, c, CIN, COUT)] = v;
+    }
+}
+
+template <int KL> struct AVec;
+template <> struct AVec<1> { typedef float T; };
+template <> struct AVec<2> { typedef float2 T; };
+
+template <int CIN, int COUT>
+__global__ void __launch_bounds__(CV_BLOCK)
+cv_fwd_kernel(const float *__restrict__ feat, const float *__restrict__ wimg,
+              const int *__restrict__ nbr, int k_out, int kvol, int cin, int cout,
+              const float *__restrict__ scale, const float *__restrict__ shift, int relu,
+              float *__restrict__ out)
+{
+    constexpr int KL = CIN / 4;          // k values per lane quarter
+    constexpr int VW = KL < 4 ? KL : 4;  // floats per LDS fragment read
+    constexpr int SG = KL / VW;          // fragment reads per column tile
+    constexpr int NT = COUT / 16;        // column tiles
+    constexpr int WELEMS = CIN * COUT;   // floats per offset image
+    constexpr int WVEC = WELEMS / 4;     // float4 per offset image
+    constexpr int WPT = (WVEC + CV_BLOCK - 1) / CV_BLOCK; // float4 per thread to stage
+
+    extern __shared__ __align__(16) unsigned char smem[];
+    float *wl = reinterpret_cast<float *>(smem);                 // [2][WELEMS]
+    int *nl = reinterpret_cast<int *>(smem + 2 * WELEMS * 4);    // [CV_ROWS][kvol]
+    int *act = nl + CV_ROWS * kvol;                              // [kvol] active offsets
+    int *nact_p = act + kvol;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int r16 = lane & 15;
+    const int q = lane >> 4;
+    const int row0 = blockIdx.x * CV_ROWS;
+
+    // ---- neighbour tile -> LDS (coalesced), rows past k_out read as -1
+    {
+        const int total = CV_ROWS * kvol;
+        const long long gbase = (long long)row0 * kvol;
+        const long long glimit = (long long)k_out * kvol;
+        for (int e = tid; e < total; e += CV_BLOCK)
+            nl[e] = (gbase + e < glimit) ? nbr[gbase + e] : -1;
+    }
+    __syncthreads();
+    // ---- workgroup-uniform list of offsets that have at least one neighbour in the tile
+    if (wave == 0) {
+        bool any = false;
+        if (lane < kvol) {
+            for (int r = 0; r < CV_ROWS; ++r) any |= nl[r * kvol + lane] >= 0;
+        }
+        unsigned long long m = __ballot(any);
+        if (lane == 0) {
+            int n = 0;
+            while (m) {
+                int o = __builtin_ctzll(m);
+                m &= m - 1;
+                act[n++] = o;
+            }
+            *nact_p = n;
+        }
+    }
+    __syncthreads();
+    const int nact = *nact_p;
+
+    f32x4 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const bool exact = (cin == CIN);
+    const int myrow = wave * CV_ROWS_PER_WAVE + r16;
+
+    auto gather = [&](int o, float(&a)[KL]) -> bool {
+        int id = nl[myrow * kvol + o];
+        bool has = id >= 0;
+        if (has) {
+            const float *src = feat + (size_t)id * cin + q * KL;
+            if (exact) {
+                if constexpr (KL >= 4) {
+#pragma unroll
+                    for (int v = 0; v < KL / 4; ++v) {
+                        float4 x = reinterpret_cast<const float4 *>(src)[v];
+                        a[4 * v + 0] = x.x;
+                        a[4 * v + 1] = x.y;
+                        a[4 * v + 2] = x.z;
+                        a[4 * v + 3] = x.w;
+                    }
+                } else if constexpr (KL == 2) {
+                    float2 x = *reinterpret_cast<const float2 *>(src);
+                    a[0] = x.x;
+                    a[1] = x.y;
+                } else {
+                    a[0] = src[0];
+                }
+            } else {
+#pragma unroll
+                for (int s = 0; s < KL; ++s) a[s] = (q * KL + s < cin) ? src[s] : 0.f;
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < KL; ++s) a[s] = 0.f;
+        }
+        return __ballot(has) != 0ull; // wave-uniform: does this 16-row tile touch offset o?
+    };
+
+    float4 wreg[WPT];
+    auto wload = [&](int o) {
+        const float4 *src = reinterpret_cast<const float4 *>(wimg + (size_t)o * WELEMS);
+#pragma unroll
+        for (int i = 0; i < WPT; ++i) {
+            int e = tid + i * CV_BLOCK;
+            if (e < WVEC) wreg[i] = src[e];
+        }
+    };
+    auto wstore = [&](int buf) {
+        float4 *dst = reinterpret_cast<float4 *>(wl + buf * WELEMS);
+#pragma unroll
+        for (int i = 0; i < WPT; ++i) {
+            int e = tid + i * CV_BLOCK;
+            if (e < WVEC) dst[e] = wreg[i];
+        }
+    };
+    auto compute = [&](int buf, const float(&a)[KL]) {
+        const float *wb = wl + buf * WELEMS;
+#pragma unroll
+        for (int sg = 0; sg < SG; ++sg) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const float *p = wb + (((t * SG + sg) * 4 + q) * 16 + r16) * VW;
+                float b[VW];
+                if constexpr (VW == 4) {
+                    float4 x = *reinterpret_cast<const float4 *>(p);
+                    b[0] = x.x;
+                    b[1] = x.y;
+                    b[2] = x.z;
+                    b[3] = x.w;
+                } else if constexpr (VW == 2) {
+                    float2 x = *reinterpret_cast<const float2 *>(p);
+                    b[0] = x.x;
+                    b[1] = x.y;
+                } else {
+                    b[0] = p[0];
+                }
+#pragma unroll
+                for (int v = 0; v < VW; ++v)
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[sg * VW + v], b[v], acc[t], 0,
+                                                                  0, 0);
+            }
+        }
+    };
+
+    float a0[KL], a1[KL];
+    bool h0 = false, h1 = false;
+    if (nact > 0) {
+        wload(act[0]);
+        h0 = gather(act[0], a0);
+        wstore(0);
+    }
+    __syncthreads();
+
+    // two offsets per trip so the A register sets keep static names
+    for (int idx = 0; idx < nact; idx += 2) {
+        // ---- even step: compute with a0 / buf 0, prefetch into a1 / buf 1
+        {
+            const bool more = idx + 1 < nact;
+            if (more) {
+                wload(act[idx + 1]);
+                h1 = gather(act[idx + 1], a1);
+            }
+            if (h0) compute(0, a0);
+            if (more) wstore(1);
+            __syncthreads();
+        }
+        if (idx + 1 >= nact) break;
+        // ---- odd step
+        {
+            const bool more = idx + 2 < nact;
+            if (more) {
+                wload(act[idx + 2]);
+                h0 = gather(act[idx + 2], a0);
+            }
+            if (h1) compute(1, a1);
+            if (more) wstore(0);
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue: (acc * scale + shift), relu, store.  C/D map: col = lane&15, row = q*4+reg
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int col = t * 16 + r16;
+        if (col < cout) {
+            const float sc = scale ? scale[col] : 1.f;
+            const float sh = shift ? shift[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = row0 + wave * CV_ROWS_PER_WAVE + q * 4 + r;
+                if (row < k_out) {
+                    float v = acc[t][r];
+                    if (scale) v = v * sc;
+                    if (shift) v = v + sh;
+                    if (relu) v = fmaxf(v, 0.f);
+                    out[(size_t)row * cout + col] = v;
+                }
+            }
+        }
+    }
+}
+
+// -------------------------------------------------------------------------- wgrad
+// dw[o][ci][co] += sum_j feat[j][ci] * dout[in_nbr[j][o]][co]
+// One wave owns (offset o, chunk of WG_ROWS rows) and all (ci,co) tiles; K dimension = rows.
+#define WG_ROWS 512
+
+template <int CIN, int COUT>
+__global__ void __launch_bounds__(64)
+cv_wgrad_kernel(const float *__restrict__ feat, const float *__restrict__ dout,
+                const int *__restrict__ in_nbr, int k_in, int kvol, int cin, int cout,
+                float *__restrict__ dw)
+{
+    constexpr int MT = CIN / 16 > 0 ? CIN / 16 : 1; // row tiles of dW (ci)
+    constexpr int NT = COUT / 16;                   // col tiles of dW (co)
+    const int o = blockIdx.y;
+    const int lane = threadIdx.x;
+    const int i16 = lane & 15;
+    const int kq = lane >> 4;
+    const int rbeg = blockIdx.x * WG_ROWS;
+    const int rend = min(rbeg + WG_ROWS, k_in);
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    bool any_total = false;
+    for (int r = rbeg; r < rend; r += 4) {
+        const int row = r + kq;
+        int nb = -1;
+        if (row < rend) nb = in_nbr[(size_t)row * kvol + o];
+        if (__ballot(nb >= 0) == 0ull) continue; // none of these 4 rows has a pair at offset o
+        any_total = true;
+        float a[MT], b[NT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            int ci = m * 16 + i16;
+            a[m] = (nb >= 0 && ci < cin) ? feat[(size_t)row * cin + ci] : 0.f;
+        }
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            int co = n * 16 + i16;
+            b[n] = (nb >= 0 && co < cout) ? dout[(size_t)nb * cout + co] : 0.f;
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], b[n], acc[m][n], 0, 0, 0);
+    }
+    if (!any_total) return;
+    float *dwo = dw + (size_t)o * cin * cout;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                int ci = m * 16 + kq * 4 + r;
+                int co = n * 16 + i16;
+                if (ci < cin && co < cout) atomicAdd(&dwo[(size_t)ci * cout + co], acc[m][n][r]);
+            }
+}
+
+// -------------------------------------------------------------------------- host side
+
+extern "C" size_t lcf_weight_image_elems(int kvol, int cin, int cout, int transpose)
+{
+    int ci = transpose ? cout : cin, co = transpose ? cin : cout;
+    int CIN = cv_pad_cin(ci), COUT = cv_pad_cout(co);
+    if (kvol <= 0 || CIN < 0 || COUT < 0) return 0;
+    return (size_t)kvol * CIN * COUT;
+}
+
+extern "C" int lcf_weight_image(const float *w, int kvol, int cin, int cout, int transpose,
+                                float *img, void *stream)
+{
+    if (!w || !img || kvol <= 0 || cin <= 0 || cout <= 0) return LCF_ERR_ARG;
+    int ci = transpose ? cout : cin, co = transpose ? cin : cout;
+    int CIN = cv_pad_cin(ci), COUT = cv_pad_cout(co);
+    if (CIN < 0 || COUT < 0 || CIN * COUT > 8192) return LCF_ERR_UNSUPPORTED;
+    long long total = (long long)kvol * CIN * COUT;
+    int nb = (int)((total + 255) / 256);
+    if (nb > 2048) nb = 2048;
+    cv_weight_image_kernel<<<nb, 256, 0, (hipStream_t)stream>>>(w, kvol, cin, cout, CIN, COUT,
+                                                                transpose, img);
+    LCF_CHECK_LAUNCH();
+    return LCF_OK;
+}
+
+template <int CIN, int COUT>
+static int cv_launch_fwd(const float *feat, const float *wimg, const int *nbr, int k_out,
+                         int kvol, int cin, int cout, const float *scale, const float *shift,
+                         int relu, float *out, hipStream_t st)
+{
+    size_t lds = (size_t)2 * CIN * COUT * 4 + (size_t)CV_ROWS * kvol * 4 + (size_t)kvol * 4 + 16;
+    int nb = (k_out + CV_ROWS - 1) / CV_ROWS;
+    if (lds > 64 * 1024) {
+        // more than the 64 KiB default: opt in (gfx950 has 160 KiB of LDS per CU)
+        if (hipFuncSetAttribute((const void *)cv_fwd_kernel<CIN, COUT>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds) != hipSuccess)
+            return LCF_ERR_LAUNCH;
+    }
+    cv_fwd_kernel<CIN, COUT><<<nb, CV_BLOCK, lds, st>>>(feat, wimg, nbr, k_out, kvol, cin, cout,
+                                                        scale, shift, relu, out);
+    LCF_CHECK_LAUNCH();
+    return LCF_OK;
+}
+
+#define CV_DISPATCH(FN, ...)                                                          \
+    switch (CIN * 1000 + COUT) {                                                      \
+    case 4016: return FN<4, 16>(__VA_ARGS__);                                         \
+    case 4032: return FN<4, 32>(__VA_ARGS__);                                         \
+    case 4064: return FN<4, 64>(__VA_ARGS__);                                         \
+    case 4128: return FN<4, 128>(__VA_ARGS__);                                        \
+    case 8016: return FN<8, 16>(__VA_ARGS__);                                         \
+    case 8032: return FN<8, 32>(__VA_ARGS__);                                         \
+    case 8064: return FN<8, 64>(__VA_ARGS__);                                         \
+    case 8128: return FN<8, 128>(__VA_ARGS__);                                        \
+    case 16016: return FN<16, 16>(__VA_ARGS__);                                       \
+    case 16032: return FN<16, 32>(__VA_ARGS__);                                       \
+    case 16064: return FN<16, 64>(__VA_ARGS__);                                       \
+    case 16128: return FN<16, 128>(__VA_ARGS__);                                      \
+    case 32016: return FN<32, 16>(__VA_ARGS__);                                       \
+    case 32032: return FN<32, 32>(__VA_ARGS__);                                       \
+    case 32064: return FN<32, 64>(__VA_ARGS__);                                       \
+    case 32128: return FN<32, 128>(__VA_ARGS__);                                      \
+    case 64016: return FN<64, 16>(__VA_ARGS__);                                       \
+    case 64032: return FN<64, 32>(__VA_ARGS__);                                       \
+    case 64064: return FN<64, 64>(__VA_ARGS__);                                       \
+    case 64128: return FN<64, 128>(__VA_ARGS__);                                      \
+    case 128016: return FN<128, 16>(__VA_ARGS__);                                     \
+    case 128032: return FN<128, 32>(__VA_ARGS__);                                     \
+    case 128064: return FN<128, 64>(__VA_ARGS__);                                     \
+    default: return LCF_ERR_UNSUPPORTED;                                              \
+    }
+
+extern "C" int lcf_indice_conv_fwd(const float *feat, const float *wimg, const int *nbr,
+                                   int k_out, int kvol, int cin, int cout, const float *scale,
+                                   const float *shift, int relu, float *out, void *stream)
+{
+    if (k_out < 0 || kvol <= 0 || cin <= 0 || cout <= 0 || !wimg ||
+        (k_out > 0 && (!feat || !nbr || !out)))
+        return LCF_ERR_ARG;
+    if (kvol > LCF_MAX_KVOL) return LCF_ERR_UNSUPPORTED;
+    if (((uintptr_t)feat & 15) || ((uintptr_t)wimg & 15)) return LCF_ERR_ARG;
+    int CIN = cv_pad_cin(cin), COUT = cv_pad_cout(cout);
+    if (CIN < 0 || COUT < 0 || CIN * COUT > 8192) return LCF_ERR_UNSUPPORTED;
+    if (k_out == 0) return LCF_OK;
+    hipStream_t st = (hipStream_t)stream;
+    CV_DISPATCH(cv_launch_fwd, feat, wimg, nbr, k_out, kvol, cin, cout, scale, shift, relu, out,
+                st);
+}
+
+template <int CIN, int COUT>
+static int cv_launch_wgrad(const float *feat, const float *dout, const int *in_nbr, int k_in,
+                           int kvol, int cin, int cout, float *dw, hipStream_t st)
+{
+    dim3 grid((k_in + WG_ROWS - 1) / WG_ROWS, kvol);
+    cv_wgrad_kernel<(CIN < 16 ? 16 : CIN), COUT><<<grid, 64, 0, st>>>(feat, dout, in_nbr, k_in,
+                                                                       kvol, cin, cout, dw);
+    LCF_CHECK_LAUNCH();
+    return LCF_OK;
+}
+
+extern "C" int lcf_indice_conv_wgrad(const float *feat, const float *dout, const int *in_nbr,
+                                     int k_in, int kvol, int cin, int cout, float *dw,
+                                     void *stream)
+{
+    if (k_in < 0 || kvol <= 0 || cin <= 0 || cout <= 0 || !dw ||
+        (k_in > 0 && (!feat || !dout || !in_nbr)))
+        return LCF_ERR_ARG;
+    if (kvol > LCF_MAX_KVOL) return LCF_ERR_UNSUPPORTED;
+    int CIN = cv_pad_cin(cin), COUT = cv_pad_cout(cout);
+    if (CIN < 0 || COUT < 0 || CIN * COUT > 8192) return LCF_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(dw, 0, (size_t)kvol * cin * cout * 4, st) != hipSuccess)
+        return LCF_ERR_LAUNCH;
+    if (k_in == 0) return LCF_OK;
+    CV_DISPATCH(cv_launch_wgrad, feat, dout, in_nbr, k_in, kvol, cin, cout, dw, st);
+}

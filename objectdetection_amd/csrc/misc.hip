@@ -1,0 +1,199 @@
+// misc.hip -- dense() scatter, VFE streaming kernels, error strings.
+#include "common.h"
+
+extern "C" const char *lcf_strerror(int rc)
+{
+    switch (rc) {
+    case LCF_OK: return "ok";
+    case LCF_ERR_ARG: return "lcf: invalid argument";
+    case LCF_ERR_WORKSPACE: return "lcf: workspace too small";
+    case LCF_ERR_UNSUPPORTED: return "lcf: unsupported shape for the gfx950 kernels";
+    case LCF_ERR_RANGE: return "lcf: grid or index range exceeds 32-bit keys";
+    case LCF_ERR_LAUNCH: return "lcf: HIP launch error";
+    default: return "lcf: unknown error";
+    }
+}
+
+extern "C" int lcf_version(void) { return 100; }
+
+// ---------------------------------------------------------------- dense
+// SparseConvTensor.dense() (second/pytorch/models/middle.py:206): [B,C,D,H,W] contiguous.
+// Thread = (row, channel); a row's C values land C*svol*4 bytes apart, so writes are scattered by
+// construction -- the bulk traffic is the zero fill, done by hipMemsetAsync at copy-engine rate.
+__global__ void __launch_bounds__(256)
+dense_scatter_kernel(const float *__restrict__ feat, const int *__restrict__ coors, int k, int c,
+                     int batch, int D, int H, int W, float *__restrict__ out)
+{
+    long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (long long)k * c) return;
+    int row = (int)(t / c), ch = (int)(t - (long long)row * c);
+    int4 q = reinterpret_cast<const int4 *>(coors)[row];
+    if (q.x < 0 || q.x >= batch || q.y < 0 || q.y >= D || q.z < 0 || q.z >= H || q.w < 0 ||
+        q.w >= W)
+        return;
+    size_t svol = (size_t)D * H * W;
+    size_t sp = ((size_t)q.y * H + q.z) * W + q.w;
+    out[((size_t)q.x * c + ch) * svol + sp] = feat[t];
+}
+
+__global__ void __launch_bounds__(256)
+dense_gather_kernel(const float *__restrict__ dout, const int *__restrict__ coors, int k, int c,
+                    int batch, int D, int H, int W, float *__restrict__ dfeat)
+{
+    long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (long long)k * c) return;
+    int row = (int)(t / c), ch = (int)(t - (long long)row * c);
+    int4 q = reinterpret_cast<const int4 *>(coors)[row];
+    float v = 0.f;
+    if (q.x >= 0 && q.x < batch && q.y >= 0 && q.y < D && q.z >= 0 && q.z < H && q.w >= 0 &&
+        q.w < W) {
+        size_t svol = (size_t)D * H * W;
+        size_t sp = ((size_t)q.y * H + q.z) * W + q.w;
+        v = dout[((size_t)q.x * c + ch) * svol + sp];
+    }
+    dfeat[t] = v;
+}
+
+extern "C" int lcf_dense(const float *feat, const int *coors, int k, int c, int batch,
+                         const int shape[3], float *out, void *stream)
+{
+    if (k < 0 || c <= 0 || batch <= 0 || !shape || !out || (k > 0 && (!feat || !coors)))
+        return LCF_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    size_t bytes = (size_t)batch * c * shape[0] * shape[1] * shape[2] * 4;
+    if (hipMemsetAsync(out, 0, bytes, st) != hipSuccess) return LCF_ERR_LAUNCH;
+    if (k == 0) return LCF_OK;
+    long long total = (long long)k * c;
+    dense_scatter_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(
+        feat, coors, k, c, batch, shape[0], shape[1], shape[2], out);
+    LCF_CHECK_LAUNCH();
+    return LCF_OK;
+}
+
+extern "C" int lcf_dense_bwd(const float *dout, const int *coors, int k, int c, int batch,
+                             const int shape[3], float *dfeat, void *stream)
+{
+    if (k < 0 || c <= 0 || batch <= 0 || !shape || !dout || (k > 0 && (!dfeat || !coors)))
+        return LCF_ERR_ARG;
+    if (k == 0) return LCF_OK;
+    long long total = (long long)k * c;
+    dense_gather_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(
+        dout, coors, k, c, batch, shape[0], shape[1], shape[2], dfeat);
+    LCF_CHECK_LAUNCH();
+    return LCF_OK;
+}
+
+// ---------------------------------------------------------------- VFE
+// SimpleVoxel.forward (voxel_encoder.py:220-225): sum over T (padding rows are zero) / num.
+// The sum runs t = 0..T-1 in order, as torch's reduction over a 5-long dim does.
+__global__ void __launch_bounds__(256)
+vfe_mean_kernel(const float *__restrict__ voxels, const int *__restrict__ num, int k, int t,
+                int f, int c, float *__restrict__ out)
+{
+    long long id = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (id >= (long long)k * c) return;
+    int v = (int)(id / c), ch = (int)(id - (long long)v * c);
+    const float *p = voxels + (size_t)v * t * f + ch;
+    float s = 0.f;
+    for (int i = 0; i < t; ++i) s += p[(size_t)i * f];
+    out[id] = __fdiv_rn(s, (float)num[v]);
+}
+
+// VoxelFeatureExtractor.forward :116-124: out[k,t,:] = [voxels[k,t,:f], voxels[k,t,:3]-mean]
+__global__ void __launch_bounds__(256)
+vfe_augment_kernel(const float *__restrict__ voxels, const int *__restrict__ num, int k, int t,
+                   int f, float *__restrict__ out)
+{
+    long long id = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (id >= (long long)k * t) return;
+    int v = (int)(id / t);
+    const float *base = voxels + (size_t)v * t * f;
+    const float *p = base + (size_t)(id - (long long)v * t) * f;
+    float *o = out + (size_t)id * (f + 3);
+    float n = (float)num[v];
+    for (int e = 0; e < f; ++e) o[e] = p[e];
+#pragma unroll
+    for (int e = 0; e < 3; ++e) {
+        float s = 0.f;
+        for (int i = 0; i < t; ++i) s += base[(size_t)i * f + e];
+        o[f + e] = p[e] - __fdiv_rn(s, n);
+    }
+}
+
+// Tail of VFELayer.forward (:69-80) + mask (:130), or the final masked max (:134-139).
+// Thread = (voxel, channel); walks the T points of its voxel (stride u floats: the 64 lanes of a
+// wave read 64 consecutive channels = 256 contiguous bytes per point row).
+__global__ void __launch_bounds__(256)
+vfe_pool_kernel(const float *__restrict__ x, const int *__restrict__ num, int k, int t, int u,
+                const float *__restrict__ scale, const float *__restrict__ shift, int mode,
+                float *__restrict__ out)
+{
+    long long id = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (id >= (long long)k * u) return;
+    int v = (int)(id / u), ch = (int)(id - (long long)v * u);
+    const float sc = scale ? scale[ch] : 1.f;
+    const float sh = shift ? shift[ch] : 0.f;
+    const int n = num[v];
+    const float *p = x + (size_t)v * t * u + ch;
+    if (mode == 0) {
+        float mx = -INFINITY;
+        for (int i = 0; i < t; ++i) {
+            float y = fmaxf(p[(size_t)i * u] * sc + sh, 0.f);
+            mx = fmaxf(mx, y);
+        }
+        float *o = out + (size_t)v * t * 2 * u;
+        for (int i = 0; i < t; ++i) {
+            float y = fmaxf(p[(size_t)i * u] * sc + sh, 0.f);
+            float m = i < n ? 1.f : 0.f;
+            o[(size_t)i * 2 * u + ch] = y * m;
+            o[(size_t)i * 2 * u + u + ch] = mx * m;
+        }
+    } else {
+        float mx = -INFINITY;
+        for (int i = 0; i < t; ++i) {
+            float y = fmaxf(p[(size_t)i * u] * sc + sh, 0.f);
+            y = i < n ? y : 0.f;
+            mx = fmaxf(mx, y);
+        }
+        out[id] = mx;
+    }
+}
+
+extern "C" int lcf_vfe_mean(const float *voxels, const int *num, int k, int t, int f, int c,
+                            float *out, void *stream)
+{
+    if (k < 0 || t <= 0 || f <= 0 || c <= 0 || c > f || (k > 0 && (!voxels || !num || !out)))
+        return LCF_ERR_ARG;
+    if (k == 0) return LCF_OK;
+    long long total = (long long)k * c;
+    vfe_mean_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(
+        voxels, num, k, t, f, c, out);
+    LCF_CHECK_LAUNCH();
+    return LCF_OK;
+}
+
+extern "C" int lcf_vfe_augment(const float *voxels, const int *num, int k, int t, int f,
+                               float *out, void *stream)
+{
+    if (k < 0 || t <= 0 || f < 3 || (k > 0 && (!voxels || !num || !out))) return LCF_ERR_ARG;
+    if (k == 0) return LCF_OK;
+    long long total = (long long)k * t;
+    vfe_augment_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(
+        voxels, num, k, t, f, out);
+    LCF_CHECK_LAUNCH();
+    return LCF_OK;
+}
+
+extern "C" int lcf_vfe_pool(const float *x, const int *num, int k, int t, int u,
+                            const float *scale, const float *shift, int mode, float *out,
+                            void *stream)
+{
+    if (k < 0 || t <= 0 || u <= 0 || mode < 0 || mode > 1 || (k > 0 && (!x || !num || !out)))
+        return LCF_ERR_ARG;
+    if (k == 0) return LCF_OK;
+    long long total = (long long)k * u;
+    vfe_pool_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(
+        x, num, k, t, u, scale, shift, mode, out);
+    LCF_CHECK_LAUNCH();
+    return LCF_OK;
+}

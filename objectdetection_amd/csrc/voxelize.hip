@@ -1,0 +1,263 @@
+// voxelize.hip -- hash-based point-to-voxel scatter, bit-identical to the sequential first-come
+// loop of the reference (second/utils/simplevis.py:23-50 twin of points_to_voxel;
+// call contract second/data/preprocess.py:626-639).
+//
+// Determinism recipe (SURVEY.md section 7 "order determinism"):
+//   1. insert : every in-range point claims its cell in an open-addressing hash (CAS on the
+//               32-bit linear cell key) and pushes its index through the cell's T-slot sorted
+//               list with a chain of atomicMin's (slot s keeps the min, the loser moves on to
+//               slot s+1).  Whatever the interleaving, slot s ends up holding the (s+1)-th
+//               smallest point index of the cell, i.e. exactly the first T points the sequential
+//               loop would have kept, in its order.
+//   2. count/assign : a point is "first" iff it sits in slot 0 of its cell; the exclusive scan of
+//               the first-flags over the point index IS the sequential voxel id.  The first point
+//               whose id equals max_voxels marks where the sequential loop `break`s (i*).
+//   3. emit   : every kept point copies its row to voxels[vid][slot]; the first point of the cell
+//               also writes coors / num_points and zero-fills the unused slots.
+#include "common.h"
+
+#define VOX_SENT 0x7F7F7F7F /* list sentinel: byte-pattern memset, larger than any point index */
+#define VOX_ITEMS 4          /* points per thread in the count / assign kernels */
+#define VOX_BLOCK 256
+
+struct VoxParams {
+    float lo[3];
+    float vs[3];
+    int grid[3]; // x,y,z
+};
+
+__global__ void __launch_bounds__(VOX_BLOCK)
+vox_insert_kernel(const float *__restrict__ pts, int n, int f, VoxParams p, int max_pts,
+                  uint32_t *__restrict__ keys, uint32_t mask, int *__restrict__ lists,
+                  int *__restrict__ cellslot)
+{
+    int i = blockIdx.x * VOX_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    int c[3];
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        // IEEE fp32 subtract and true divide, no contraction: bit-exact at voxel edges
+        float d = __fsub_rn(pts[(size_t)i * f + j], p.lo[j]);
+        float q = __fdiv_rn(d, p.vs[j]);
+        float fl = floorf(q);
+        if (!(fl >= 0.0f) || fl >= (float)p.grid[j]) ok = false;
+        c[j] = (int)fl;
+    }
+    if (!ok) {
+        cellslot[i] = -1;
+        return;
+    }
+    uint32_t key = ((uint32_t)c[2] * (uint32_t)p.grid[1] + (uint32_t)c[1]) * (uint32_t)p.grid[0] +
+                   (uint32_t)c[0];
+    uint32_t h = lcf_hash_insert(keys, mask, key);
+    cellslot[i] = (int)h;
+    int cur = i;
+    int *l = lists + (size_t)h * max_pts;
+    for (int s = 0; s < max_pts; ++s) {
+        int old = atomicMin(&l[s], cur);
+        if (old == VOX_SENT) break; // landed in an empty slot
+        cur = old > cur ? old : cur; // loser moves on
+    }
+}
+
+__device__ __forceinline__ int vox_is_first(const int *cellslot, const int *lists, int max_pts,
+                                            int i, int n)
+{
+    if (i >= n) return 0;
+    int h = cellslot[i];
+    if (h < 0) return 0;
+    return lists[(size_t)h * max_pts] == i;
+}
+
+__global__ void __launch_bounds__(VOX_BLOCK)
+vox_count_kernel(const int *__restrict__ cellslot, const int *__restrict__ lists, int max_pts,
+                 int n, int *__restrict__ bsums, int *__restrict__ ctrl)
+{
+    __shared__ int lds[8];
+    int base = (blockIdx.x * VOX_BLOCK + threadIdx.x) * VOX_ITEMS;
+    int cnt = 0;
+#pragma unroll
+    for (int j = 0; j < VOX_ITEMS; ++j) cnt += vox_is_first(cellslot, lists, max_pts, base + j, n);
+    int total;
+    lcf_block_excl_scan_256(cnt, lds, &total);
+    if (threadIdx.x == 0) {
+        bsums[blockIdx.x] = total;
+        if (blockIdx.x == 0) ctrl[0] = 0x7FFFFFFF; // i* = "never"
+    }
+}
+
+__global__ void __launch_bounds__(VOX_BLOCK)
+vox_assign_kernel(const int *__restrict__ cellslot, const int *__restrict__ lists, int max_pts,
+                  int n, const int *__restrict__ bsums, int max_vox, int *__restrict__ pvid,
+                  int *__restrict__ ctrl, int *__restrict__ voxel_num)
+{
+    __shared__ int lds[8];
+    // prefix of the preceding blocks' sums
+    int part = 0;
+    for (int b = threadIdx.x; b < (int)blockIdx.x; b += VOX_BLOCK) part += bsums[b];
+    int blockbase;
+    lcf_block_excl_scan_256(part, lds, &blockbase);
+    int base = (blockIdx.x * VOX_BLOCK + threadIdx.x) * VOX_ITEMS;
+    int fl[VOX_ITEMS];
+    int cnt = 0;
+#pragma unroll
+    for (int j = 0; j < VOX_ITEMS; ++j) {
+        fl[j] = vox_is_first(cellslot, lists, max_pts, base + j, n);
+        cnt += fl[j];
+    }
+    int total;
+    int ex = lcf_block_excl_scan_256(cnt, lds, &total) + blockbase;
+#pragma unroll
+    for (int j = 0; j < VOX_ITEMS; ++j) {
+        if (fl[j]) {
+            pvid[base + j] = ex;
+            if (ex == max_vox) ctrl[0] = base + j; // unique writer: the sequential loop stops here
+            ++ex;
+        }
+    }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+        int nfirst = blockbase + total;
+        voxel_num[0] = nfirst < max_vox ? nfirst : max_vox;
+    }
+}
+
+__global__ void __launch_bounds__(VOX_BLOCK)
+vox_emit_kernel(const float *__restrict__ pts, int n, int f, VoxParams p, int max_pts,
+                int max_vox, int cap_mode, const uint32_t *__restrict__ keys,
+                const int *__restrict__ lists, const int *__restrict__ cellslot,
+                const int *__restrict__ pvid, const int *__restrict__ ctrl,
+                const int *__restrict__ voxel_num, float *__restrict__ voxels,
+                int *__restrict__ coors, int *__restrict__ num_pts)
+{
+    int i = blockIdx.x * VOX_BLOCK + threadIdx.x;
+    // (a) zero the rows beyond voxel_num (padded outputs of generate_multi_gpu)
+    if (i < max_vox && i >= voxel_num[0]) {
+        float *row = voxels + (size_t)i * max_pts * f;
+        for (int e = 0; e < max_pts * f; ++e) row[e] = 0.f;
+        coors[i * 3 + 0] = 0;
+        coors[i * 3 + 1] = 0;
+        coors[i * 3 + 2] = 0;
+        num_pts[i] = 0;
+    }
+    if (i >= n) return;
+    int h = cellslot[i];
+    if (h < 0) return;
+    const int istar = cap_mode == 0 ? ctrl[0] : 0x7FFFFFFF;
+    if (i >= istar) return; // the sequential loop had already stopped
+    const int *l = lists + (size_t)h * max_pts;
+    int first = l[0];
+    int vid = pvid[first];
+    if (vid >= max_vox) return; // voxel never created
+    int slot = -1;
+    for (int s = 0; s < max_pts; ++s) {
+        if (l[s] == i) {
+            slot = s;
+            break;
+        }
+    }
+    if (slot < 0) return; // voxel already full when this point arrived
+    float *dst = voxels + ((size_t)vid * max_pts + slot) * f;
+    const float *src = pts + (size_t)i * f;
+    for (int e = 0; e < f; ++e) dst[e] = src[e];
+    if (slot == 0) {
+        int cnt = 0;
+        for (int s = 0; s < max_pts; ++s) {
+            int idx = l[s];
+            if (idx != VOX_SENT && idx < istar) ++cnt;
+        }
+        num_pts[vid] = cnt;
+        float *row = voxels + (size_t)vid * max_pts * f;
+        for (int e = cnt * f; e < max_pts * f; ++e) row[e] = 0.f;
+        uint32_t key = keys[h];
+        uint32_t gx = (uint32_t)p.grid[0], gy = (uint32_t)p.grid[1];
+        coors[vid * 3 + 2] = (int)(key % gx);
+        coors[vid * 3 + 1] = (int)((key / gx) % gy);
+        coors[vid * 3 + 0] = (int)(key / (gx * gy));
+    }
+}
+
+struct VoxWs {
+    uint32_t *keys;
+    int *lists, *cellslot, *pvid, *bsums, *ctrl;
+    uint32_t hc;
+    int nblk;
+    size_t bytes;
+};
+
+static VoxWs vox_carve(void *ws, int n, int max_pts)
+{
+    VoxWs w;
+    uint32_t need = (uint32_t)(n > 0 ? n : 1) * 2u;
+    w.hc = lcf_pow2_ge(need < 1024u ? 1024u : need);
+    w.nblk = (n + VOX_BLOCK * VOX_ITEMS - 1) / (VOX_BLOCK * VOX_ITEMS);
+    if (w.nblk < 1) w.nblk = 1;
+    char *p = (char *)ws;
+    size_t off = 0;
+    w.keys = (uint32_t *)(p + off);
+    off += lcf_align_up((size_t)w.hc * 4, 256);
+    w.lists = (int *)(p + off);
+    off += lcf_align_up((size_t)w.hc * max_pts * 4, 256);
+    w.cellslot = (int *)(p + off);
+    off += lcf_align_up((size_t)(n + VOX_ITEMS) * 4, 256);
+    w.pvid = (int *)(p + off);
+    off += lcf_align_up((size_t)(n + VOX_ITEMS) * 4, 256);
+    w.bsums = (int *)(p + off);
+    off += lcf_align_up((size_t)w.nblk * 4, 256);
+    w.ctrl = (int *)(p + off);
+    off += 256;
+    w.bytes = off;
+    return w;
+}
+
+extern "C" size_t lcf_voxelize_workspace_bytes(int n, int max_pts)
+{
+    if (n < 0 || max_pts <= 0) return 0;
+    return vox_carve(nullptr, n, max_pts).bytes;
+}
+
+extern "C" int lcf_voxelize(const float *points, int n, int f, const float vs[3],
+                            const float range[6], int max_pts, int max_vox, int cap_mode,
+                            float *voxels, int *coors, int *num_pts, int *voxel_num, void *ws,
+                            size_t ws_bytes, void *stream)
+{
+    if (n < 0 || f < 3 || max_pts <= 0 || max_vox <= 0 || !vs || !range || !voxels || !coors ||
+        !num_pts || !voxel_num || !ws || (n > 0 && !points) || cap_mode < 0 || cap_mode > 1)
+        return LCF_ERR_ARG;
+    if (n >= VOX_SENT - VOX_BLOCK * VOX_ITEMS) return LCF_ERR_RANGE;
+    VoxParams p;
+    unsigned long long cells = 1;
+    for (int j = 0; j < 3; ++j) {
+        p.lo[j] = range[j];
+        p.vs[j] = vs[j];
+        // grid_size = round((hi - lo) / vs) in fp32 (simplevis.py:26-29)
+        volatile float g = (range[3 + j] - range[j]) / vs[j];
+        p.grid[j] = (int)rintf(g);
+        if (p.grid[j] <= 0) return LCF_ERR_ARG;
+        cells *= (unsigned long long)p.grid[j];
+    }
+    if (cells >= 0xFFFFFFFFull) return LCF_ERR_RANGE;
+    VoxWs w = vox_carve(ws, n, max_pts);
+    if (ws_bytes < w.bytes) return LCF_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(w.keys, 0xFF, (size_t)w.hc * 4, st) != hipSuccess) return LCF_ERR_LAUNCH;
+    if (hipMemsetAsync(w.lists, 0x7F, (size_t)w.hc * max_pts * 4, st) != hipSuccess)
+        return LCF_ERR_LAUNCH;
+    if (n > 0) {
+        vox_insert_kernel<<<(n + VOX_BLOCK - 1) / VOX_BLOCK, VOX_BLOCK, 0, st>>>(
+            points, n, f, p, max_pts, w.keys, w.hc - 1, w.lists, w.cellslot);
+        LCF_CHECK_LAUNCH();
+    }
+    vox_count_kernel<<<w.nblk, VOX_BLOCK, 0, st>>>(w.cellslot, w.lists, max_pts, n, w.bsums,
+                                                   w.ctrl);
+    LCF_CHECK_LAUNCH();
+    vox_assign_kernel<<<w.nblk, VOX_BLOCK, 0, st>>>(w.cellslot, w.lists, max_pts, n, w.bsums,
+                                                    max_vox, w.pvid, w.ctrl, voxel_num);
+    LCF_CHECK_LAUNCH();
+    int m = n > max_vox ? n : max_vox;
+    vox_emit_kernel<<<(m + VOX_BLOCK - 1) / VOX_BLOCK, VOX_BLOCK, 0, st>>>(
+        points, n, f, p, max_pts, max_vox, cap_mode, w.keys, w.lists, w.cellslot, w.pvid, w.ctrl,
+        voxel_num, voxels, coors, num_pts);
+    LCF_CHECK_LAUNCH();
+    return LCF_OK;
+}
