@@ -1,0 +1,333 @@
+"""Torch-level wrappers over the liblcf C ABI (include/lcf.h).
+
+PyTorch is plumbing here: it owns device memory and streams; every computation is a HIP kernel
+in liblcf.so enqueued on torch's current stream.  Nothing in this module has a CPU fallback:
+tensors must live on the GPU, and the library must have been built.
+"""
+import torch
+
+from . import _lib
+from ._lib import check, f3, f6, i3
+
+MAX_KVOL = 64
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError(
+                "objectdetection_amd ops run on the GPU only (no CPU fallback); got a "
+                f"{t.device} tensor")
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _ws(nbytes, device):
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+def _prod(v):
+    p = 1
+    for x in v:
+        p *= int(x)
+    return p
+
+
+def to3(v):
+    if isinstance(v, int):
+        return [v, v, v]
+    v = [int(x) for x in v]
+    if len(v) != 3:
+        raise ValueError(f"expected an int or 3 ints, got {v}")
+    return v
+
+
+# ------------------------------------------------------------------ voxelizer
+
+def voxelize(points, voxel_size, pc_range, max_points, max_voxels, cap_mode=0):
+    """points [N,F] f32 cuda -> (voxels [max_voxels,T,F], coors [max_voxels,3] zyx,
+    num_points [max_voxels], voxel_num [1] i32 device).  Rows >= voxel_num are zero.
+    Bit-identical to the reference's sequential loop (include/lcf.h: lcf_voxelize)."""
+    _need_cuda(points)
+    if points.dtype != torch.float32 or points.dim() != 2:
+        raise ValueError("points must be a [N,F] float32 tensor")
+    pts = points.contiguous()
+    n, f = pts.shape
+    dev = pts.device
+    L = _lib.lib()
+    voxels = torch.empty((max_voxels, max_points, f), dtype=torch.float32, device=dev)
+    coors = torch.empty((max_voxels, 3), dtype=torch.int32, device=dev)
+    num = torch.empty((max_voxels,), dtype=torch.int32, device=dev)
+    vnum = torch.empty((1,), dtype=torch.int32, device=dev)
+    wsb = L.lcf_voxelize_workspace_bytes(n, max_points)
+    ws = _ws(wsb, dev)
+    check(L.lcf_voxelize(_ptr(pts), n, f, f3(voxel_size), f6(pc_range), int(max_points),
+                         int(max_voxels), int(cap_mode), _ptr(voxels), _ptr(coors), _ptr(num),
+                         _ptr(vnum), _ptr(ws), ws.numel(), _stream()))
+    return voxels, coors, num, vnum
+
+
+# ------------------------------------------------------------------ rulebooks
+
+def conv_out_shape(shape, ksize, stride, pad, dil):
+    out = i3(0)
+    _lib.lib().lcf_conv_out_shape(i3(shape), i3(ksize), i3(stride), i3(pad), i3(dil), out)
+    return [int(x) for x in out]
+
+
+class Rulebook:
+    """Native rulebook of one sparse convolution: neighbour tables (see include/lcf.h) plus,
+    lazily, spconv's canonical ``indice_pairs`` / ``indice_pair_num``.
+
+    Tuple-compatible with what spconv stores in ``SparseConvTensor.indice_dict``:
+    ``(outids, indices, indice_pairs, indice_pair_num, spatial_shape)``.
+    """
+
+    def __init__(self, subm, in_indices, out_indices, in_shape, out_shape, ksize, stride,
+                 padding, dilation, out_nbr, in_nbr):
+        self.subm = subm
+        self.in_indices = in_indices
+        self.out_indices = out_indices
+        self.in_shape = list(in_shape)
+        self.out_shape = list(out_shape)
+        self.ksize, self.stride, self.padding, self.dilation = ksize, stride, padding, dilation
+        self.kvol = _prod(ksize)
+        self.out_nbr = out_nbr
+        self._in_nbr = in_nbr
+        self._pairs = None
+
+    @property
+    def k_in(self):
+        return self.in_indices.shape[0]
+
+    @property
+    def k_out(self):
+        return self.out_indices.shape[0]
+
+    @property
+    def in_nbr(self):
+        if self._in_nbr is None:  # submanifold: the mirror image of out_nbr
+            t = torch.empty_like(self.out_nbr)
+            check(_lib.lib().lcf_rulebook_mirror(_ptr(self.out_nbr), self.k_in, self.kvol,
+                                                 _ptr(t), _stream()))
+            self._in_nbr = t
+        return self._in_nbr
+
+    def _build_pairs(self):
+        if self._pairs is None:
+            L = _lib.lib()
+            dev = self.in_indices.device
+            pairs = torch.empty((2, self.kvol, self.k_in), dtype=torch.int32, device=dev)
+            pnum = torch.empty((self.kvol,), dtype=torch.int32, device=dev)
+            ws = _ws(L.lcf_rulebook_pairs_workspace_bytes(self.k_in, self.kvol), dev)
+            check(L.lcf_rulebook_pairs(_ptr(self.in_nbr), self.k_in, self.kvol, _ptr(pairs),
+                                       _ptr(pnum), _ptr(ws), ws.numel(), _stream()))
+            self._pairs = (pairs, pnum)
+        return self._pairs
+
+    @property
+    def indice_pairs(self):
+        return self._build_pairs()[0]
+
+    @property
+    def indice_pair_num(self):
+        return self._build_pairs()[1]
+
+    def as_tuple(self):
+        return (self.out_indices, self.in_indices, self.indice_pairs, self.indice_pair_num,
+                self.out_shape)
+
+    def __iter__(self):
+        return iter(self.as_tuple())
+
+    def __getitem__(self, i):
+        return self.as_tuple()[i]
+
+    def __len__(self):
+        return 5
+
+
+def build_rulebook(indices, batch_size, spatial_shape, ksize, stride, padding, dilation, subm):
+    """indices [K,4] i32 cuda (b,z,y,x) -> Rulebook.  spconv.ops.get_indice_pairs equivalent."""
+    _need_cuda(indices)
+    if indices.dtype != torch.int32 or indices.dim() != 2 or indices.shape[1] != 4:
+        raise ValueError("indices must be [K,4] int32 (batch, z, y, x)")
+    ind = indices.contiguous()
+    k = ind.shape[0]
+    dev = ind.device
+    L = _lib.lib()
+    shape = to3(list(spatial_shape))
+    ksize, stride, padding, dilation = to3(ksize), to3(stride), to3(padding), to3(dilation)
+    kvol = _prod(ksize)
+    if kvol > MAX_KVOL:
+        raise RuntimeError(f"kernel volume {kvol} > {MAX_KVOL} is not supported")
+    if subm:
+        nbr = torch.empty((k, kvol), dtype=torch.int32, device=dev)
+        ws = _ws(L.lcf_rulebook_subm_workspace_bytes(k), dev)
+        check(L.lcf_rulebook_subm(_ptr(ind), k, int(batch_size), i3(shape), i3(ksize),
+                                  i3(dilation), _ptr(nbr), _ptr(ws), ws.numel(), _stream()))
+        return Rulebook(True, ind, ind, shape, shape, ksize, [1, 1, 1],
+                        [(a // 2) * d for a, d in zip(ksize, dilation)], dilation, nbr, None)
+    oshape = conv_out_shape(shape, ksize, stride, padding, dilation)
+    if min(oshape) <= 0:
+        raise ValueError(f"sparse conv output shape {oshape} is empty")
+    cap = L.lcf_rulebook_conv_max_out(k, i3(ksize), i3(stride))
+    ws = _ws(L.lcf_rulebook_conv_workspace_bytes(k, i3(ksize), i3(stride)), dev)
+    out_c = torch.empty((max(cap, 1), 4), dtype=torch.int32, device=dev)
+    kout_t = torch.empty((1,), dtype=torch.int32, device=dev)
+    args = (_ptr(ind), k, int(batch_size), i3(shape), i3(ksize), i3(stride), i3(padding),
+            i3(dilation))
+    check(L.lcf_rulebook_conv_discover(*args, _ptr(out_c), int(max(cap, 1)), _ptr(kout_t),
+                                       _ptr(ws), ws.numel(), _stream()))
+    k_out = int(kout_t.item())  # the one host sync per strided conv, as in spconv
+    out_nbr = torch.empty((k_out, kvol), dtype=torch.int32, device=dev)
+    in_nbr = torch.empty((k, kvol), dtype=torch.int32, device=dev)
+    check(L.lcf_rulebook_conv_fill(*args, k_out, _ptr(out_nbr), _ptr(in_nbr), _ptr(ws),
+                                   ws.numel(), _stream()))
+    return Rulebook(False, ind, out_c[:k_out].clone(), shape, oshape, ksize, stride, padding,
+                    dilation, out_nbr, in_nbr)
+
+
+# ------------------------------------------------------------------ indice_conv
+
+def weight_image(weight, transpose=False):
+    """weight [kD,kH,kW,Cin,Cout] (reference layout) -> MFMA weight image (see conv.hip)."""
+    _need_cuda(weight)
+    w = weight.detach()
+    if w.dtype != torch.float32:
+        w = w.float()
+    w = w.contiguous()
+    cin, cout = int(w.shape[-2]), int(w.shape[-1])
+    kvol = w.numel() // (cin * cout)
+    L = _lib.lib()
+    n = L.lcf_weight_image_elems(kvol, cin, cout, int(transpose))
+    if n == 0:
+        raise RuntimeError(f"unsupported channel counts for indice_conv: {cin}->{cout}")
+    img = torch.empty((n,), dtype=torch.float32, device=w.device)
+    check(L.lcf_weight_image(_ptr(w), kvol, cin, cout, int(transpose), _ptr(img), _stream()))
+    return img
+
+
+def conv_forward(features, wimg, nbr, n_rows, kvol, cin, cout, scale=None, shift=None,
+                 relu=False):
+    """out[n_rows,cout] = act((sum_o features[nbr[n][o]] @ W[o]) * scale + shift)."""
+    _need_cuda(features, wimg, nbr)
+    x = features.contiguous()
+    out = torch.empty((n_rows, cout), dtype=torch.float32, device=x.device)
+    check(_lib.lib().lcf_indice_conv_fwd(_ptr(x), _ptr(wimg), _ptr(nbr), int(n_rows), int(kvol),
+                                         int(cin), int(cout), _ptr(scale), _ptr(shift),
+                                         int(bool(relu)), _ptr(out), _stream()))
+    return out
+
+
+def conv_wgrad(features, dout, in_nbr, kvol, cin, cout):
+    x = features.contiguous()
+    g = dout.contiguous()
+    dw = torch.empty((kvol, cin, cout), dtype=torch.float32, device=x.device)
+    check(_lib.lib().lcf_indice_conv_wgrad(_ptr(x), _ptr(g), _ptr(in_nbr), x.shape[0],
+                                           int(kvol), int(cin), int(cout), _ptr(dw), _stream()))
+    return dw
+
+
+class IndiceConvFunction(torch.autograd.Function):
+    """indice_conv forward / dgrad / wgrad (torch.ops.spconv.indice_conv{,_backward})."""
+
+    @staticmethod
+    def forward(ctx, features, weight, rulebook):
+        cin, cout = int(weight.shape[-2]), int(weight.shape[-1])
+        x = features.float() if features.dtype != torch.float32 else features
+        out = conv_forward(x, weight_image(weight), rulebook.out_nbr, rulebook.k_out,
+                           rulebook.kvol, cin, cout)
+        ctx.save_for_backward(x, weight)
+        ctx.rulebook = rulebook
+        ctx.in_dtype = features.dtype
+        return out.to(features.dtype)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        x, weight = ctx.saved_tensors
+        rb = ctx.rulebook
+        cin, cout = int(weight.shape[-2]), int(weight.shape[-1])
+        g = grad_out.float().contiguous()
+        din = dw = None
+        if ctx.needs_input_grad[0]:
+            din = conv_forward(g, weight_image(weight, transpose=True), rb.in_nbr, rb.k_in,
+                               rb.kvol, cout, cin).to(ctx.in_dtype)
+        if ctx.needs_input_grad[1]:
+            dw = conv_wgrad(x, g, rb.in_nbr, rb.kvol, cin, cout).view_as(weight).to(weight.dtype)
+        return din, dw, None
+
+
+def indice_conv(features, weight, rulebook):
+    _need_cuda(features, weight)
+    return IndiceConvFunction.apply(features, weight, rulebook)
+
+
+# ------------------------------------------------------------------ dense
+
+class DenseFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, features, indices, batch_size, shape):
+        x = features.float().contiguous()
+        k, c = x.shape
+        out = torch.empty((batch_size, c, *shape), dtype=torch.float32, device=x.device)
+        check(_lib.lib().lcf_dense(_ptr(x), _ptr(indices), k, c, int(batch_size), i3(shape),
+                                   _ptr(out), _stream()))
+        ctx.save_for_backward(indices)
+        ctx.meta = (k, c, int(batch_size), list(shape), features.dtype)
+        return out.to(features.dtype)
+
+    @staticmethod
+    def backward(ctx, grad):
+        (indices,) = ctx.saved_tensors
+        k, c, b, shape, dt = ctx.meta
+        g = grad.float().contiguous()
+        df = torch.empty((k, c), dtype=torch.float32, device=g.device)
+        check(_lib.lib().lcf_dense_bwd(_ptr(g), _ptr(indices), k, c, b, i3(shape), _ptr(df),
+                                       _stream()))
+        return df.to(dt), None, None, None
+
+
+def dense(features, indices, batch_size, shape):
+    """SparseConvTensor.dense(): [B,C,D,H,W]."""
+    _need_cuda(features, indices)
+    return DenseFunction.apply(features, indices.contiguous(), int(batch_size), to3(list(shape)))
+
+
+# ------------------------------------------------------------------ VFE streaming kernels
+
+def vfe_mean(voxels, num_points, c):
+    _need_cuda(voxels, num_points)
+    v = voxels.contiguous()
+    k, t, f = v.shape
+    out = torch.empty((k, c), dtype=torch.float32, device=v.device)
+    check(_lib.lib().lcf_vfe_mean(_ptr(v), _ptr(num_points.int().contiguous()), k, t, f, int(c),
+                                  _ptr(out), _stream()))
+    return out
+
+
+def vfe_augment(voxels, num_points):
+    _need_cuda(voxels, num_points)
+    v = voxels.contiguous()
+    k, t, f = v.shape
+    out = torch.empty((k, t, f + 3), dtype=torch.float32, device=v.device)
+    check(_lib.lib().lcf_vfe_augment(_ptr(v), _ptr(num_points.int().contiguous()), k, t, f,
+                                     _ptr(out), _stream()))
+    return out
+
+
+def vfe_pool(x, num_points, scale, shift, mode):
+    _need_cuda(x, num_points)
+    x = x.contiguous()
+    k, t, u = x.shape
+    shape = (k, t, 2 * u) if mode == 0 else (k, u)
+    out = torch.empty(shape, dtype=torch.float32, device=x.device)
+    check(_lib.lib().lcf_vfe_pool(_ptr(x), _ptr(num_points.int().contiguous()), k, t, u,
+                                  _ptr(scale), _ptr(shift), int(mode), _ptr(out), _stream()))
+    return out

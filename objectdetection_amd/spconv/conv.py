@@ -1,0 +1,175 @@
+"""spconv.SparseConv3d / SubMConv3d (call sites second/pytorch/models/middle.py:64-93,127-192,
+second/pytorch/models/resnet.py:10-29).  Weight layout [kD,kH,kW,Cin,Cout], ``bias`` optional:
+the state_dict keys and shapes match spconv 1.x so reference checkpoints load."""
+import math
+
+import torch
+from torch import nn
+from torch.nn import init
+
+from .. import ops
+from .modules import SparseModule
+from .tensor import SparseConvTensor
+
+
+def _ntuple(v, n):
+    if isinstance(v, (list, tuple)):
+        v = [int(x) for x in v]
+        if len(v) != n:
+            raise ValueError(f"expected {n} values, got {v}")
+        return v
+    return [int(v)] * n
+
+
+class SparseConvolution(SparseModule):
+    def __init__(self, ndim, in_channels, out_channels, kernel_size=3, stride=1, padding=0,
+                 dilation=1, groups=1, bias=True, subm=False, output_padding=0,
+                 transposed=False, inverse=False, indice_key=None, fused_bn=False):
+        super().__init__()
+        assert groups == 1, "spconv only supports groups == 1"
+        if transposed or inverse:
+            raise NotImplementedError(
+                "transposed / inverse sparse convolutions are not on the SECOND front-end path")
+        if ndim not in (2, 3):
+            raise NotImplementedError("only 2-D and 3-D sparse convolutions are supported")
+        self.ndim = ndim
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.kernel_size = _ntuple(kernel_size, ndim)
+        self.conv1x1 = all(k == 1 for k in self.kernel_size)
+        self.stride = _ntuple(stride, ndim)
+        self.padding = _ntuple(padding, ndim)
+        self.dilation = _ntuple(dilation, ndim)
+        self.output_padding = _ntuple(output_padding, ndim)
+        self.transposed = transposed
+        self.inverse = inverse
+        self.groups = groups
+        self.subm = subm
+        self.indice_key = indice_key
+        self.fused_bn = fused_bn
+        for s, d in zip(self.stride, self.dilation):
+            assert s == 1 or d == 1, "don't support stride > 1 together with dilation > 1"
+        self.weight = nn.Parameter(torch.Tensor(*self.kernel_size, in_channels, out_channels))
+        if bias:
+            self.bias = nn.Parameter(torch.Tensor(out_channels))
+        else:
+            self.register_parameter("bias", None)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        if self.bias is not None:
+            fan_in, _ = init._calculate_fan_in_and_fan_out(self.weight)
+            bound = 1 / math.sqrt(fan_in)
+            init.uniform_(self.bias, -bound, bound)
+
+    def extra_repr(self):
+        return (f"{self.in_channels}, {self.out_channels}, kernel_size={self.kernel_size}, "
+                f"stride={self.stride}, padding={self.padding}, dilation={self.dilation}, "
+                f"subm={self.subm}, indice_key={self.indice_key}")
+
+    def _as3(self, v, fill):
+        return list(v) if self.ndim == 3 else [fill] + list(v)
+
+    def get_rulebook(self, input):
+        """Rulebook for this layer on ``input``: cached per ``indice_key`` in
+        ``input.indice_dict`` exactly as spconv does (key None is never cached)."""
+        rb = input.find_indice_pair(self.indice_key)
+        if rb is not None:
+            if self.subm and not (isinstance(rb, ops.Rulebook) and rb.subm):
+                rb = None
+            elif rb.ksize != self._as3(self.kernel_size, 1):
+                raise ValueError(
+                    f"indice_key {self.indice_key!r} reused with a different kernel size")
+        if rb is None:
+            shape = input.spatial_shape if self.ndim == 3 else [1] + list(input.spatial_shape)
+            indices = input.indices
+            if indices.dtype != torch.int32:
+                indices = indices.int()
+            if self.ndim == 2:  # (b,y,x) -> (b,0,y,x)
+                z = torch.zeros_like(indices[:, :1])
+                indices = torch.cat([indices[:, :1], z, indices[:, 1:]], dim=1)
+            rb = ops.build_rulebook(indices, input.batch_size, shape,
+                                    self._as3(self.kernel_size, 1), self._as3(self.stride, 1),
+                                    self._as3(self.padding, 0), self._as3(self.dilation, 1),
+                                    self.subm)
+            if self.indice_key is not None:
+                input.indice_dict[self.indice_key] = rb
+        return rb
+
+    def forward(self, input, _scale=None, _shift=None, _relu=False):
+        assert isinstance(input, SparseConvTensor)
+        features = input.features
+        if not features.is_cuda:
+            raise RuntimeError("spconv (objectdetection_amd) runs on the GPU only: no CPU path")
+        rb = self.get_rulebook(input)
+        if self.ndim == 3:
+            out_indices, out_shape = rb.out_indices, rb.out_shape
+        else:
+            out_indices = rb.out_indices[:, [0, 2, 3]].contiguous()
+            out_shape = rb.out_shape[1:]
+        fused = _scale is not None or _shift is not None or _relu
+        if fused:
+            # inference epilogue fusion (SparseSequential): conv (+bias) -> affine -> relu
+            shift = _shift
+            if self.bias is not None:
+                b = self.bias.float()
+                shift = b * _scale + _shift if _scale is not None else (
+                    b + _shift if _shift is not None else b)
+            x = features if features.dtype == torch.float32 else features.float()
+            out = ops.conv_forward(x, self._weight_image(), rb.out_nbr, rb.k_out, rb.kvol,
+                                   self.in_channels, self.out_channels, _scale,
+                                   None if shift is None else shift.contiguous(), _relu)
+            out = out.to(features.dtype)
+        elif not torch.is_grad_enabled():
+            x = features if features.dtype == torch.float32 else features.float()
+            shift = None if self.bias is None else self.bias.float().contiguous()
+            out = ops.conv_forward(x, self._weight_image(), rb.out_nbr, rb.k_out, rb.kvol,
+                                   self.in_channels, self.out_channels, None, shift, False)
+            out = out.to(features.dtype)
+        else:
+            out = ops.indice_conv(features, self.weight, rb)
+            if self.bias is not None:
+                out = out + self.bias
+        out_tensor = SparseConvTensor(out, out_indices, out_shape, input.batch_size)
+        out_tensor.indice_dict = input.indice_dict
+        out_tensor.grid = input.grid
+        return out_tensor
+
+    def _weight_image(self):
+        """MFMA weight image, cached until the parameter is modified in place or replaced."""
+        w = self.weight
+        tag = (w.data_ptr(), w._version, w.device, w.dtype)
+        cache = getattr(self, "_wimg", None)
+        if cache is None or cache[0] != tag:
+            cache = (tag, ops.weight_image(w))
+            object.__setattr__(self, "_wimg", cache)
+        return cache[1]
+
+
+class SparseConv2d(SparseConvolution):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1,
+                 groups=1, bias=True, indice_key=None):
+        super().__init__(2, in_channels, out_channels, kernel_size, stride, padding, dilation,
+                         groups, bias, indice_key=indice_key)
+
+
+class SparseConv3d(SparseConvolution):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1,
+                 groups=1, bias=True, indice_key=None):
+        super().__init__(3, in_channels, out_channels, kernel_size, stride, padding, dilation,
+                         groups, bias, indice_key=indice_key)
+
+
+class SubMConv2d(SparseConvolution):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1,
+                 groups=1, bias=True, indice_key=None):
+        super().__init__(2, in_channels, out_channels, kernel_size, stride, padding, dilation,
+                         groups, bias, True, indice_key=indice_key)
+
+
+class SubMConv3d(SparseConvolution):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1,
+                 groups=1, bias=True, indice_key=None):
+        super().__init__(3, in_channels, out_channels, kernel_size, stride, padding, dilation,
+                         groups, bias, True, indice_key=indice_key)

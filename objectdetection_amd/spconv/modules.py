@@ -1,0 +1,124 @@
+"""spconv.SparseModule / SparseSequential / ToDense (second/pytorch/models/middle.py:93,145;
+second/pytorch/models/resnet.py:32,69)."""
+from collections import OrderedDict
+
+import torch
+from torch import nn
+
+from .tensor import SparseConvTensor
+
+
+class SparseModule(nn.Module):
+    """Marker base class: SparseSequential hands the whole SparseConvTensor to subclasses."""
+    pass
+
+
+def is_spconv_module(module):
+    return isinstance(module, SparseModule)
+
+
+def is_sparse_conv(module):
+    from .conv import SparseConvolution
+    return isinstance(module, SparseConvolution)
+
+
+def _bn_affine(bn):
+    """Eval-mode BatchNorm1d as y = x*scale + shift (fp32)."""
+    inv = torch.rsqrt(bn.running_var.float() + bn.eps)
+    w = bn.weight.float() if bn.weight is not None else torch.ones_like(inv)
+    b = bn.bias.float() if bn.bias is not None else torch.zeros_like(inv)
+    scale = (w * inv).contiguous()
+    shift = (b - bn.running_mean.float() * scale).contiguous()
+    return scale, shift
+
+
+class SparseSequential(SparseModule):
+    """Sequential container that runs sparse modules on the SparseConvTensor and ordinary
+    nn.Modules (BatchNorm1d, ReLU, ...) on its ``.features``.
+
+    MI355X addition: when gradients are off and the modules are in eval
+    mode, a ``sparse conv -> BatchNorm1d -> ReLU`` run is executed as ONE kernel launch with the
+    normalisation folded into the conv epilogue (exact in inference: BN is affine there).
+    Set ``fuse_inference = False`` to run module by module.
+    """
+    fuse_inference = True
+
+    def __init__(self, *args, **kwargs):
+        super().__init__()
+        if len(args) == 1 and isinstance(args[0], OrderedDict):
+            for key, module in args[0].items():
+                self.add_module(key, module)
+        else:
+            for idx, module in enumerate(args):
+                self.add_module(str(idx), module)
+        for name, module in kwargs.items():
+            if name in self._modules:
+                raise ValueError("name exists.")
+            self.add_module(name, module)
+
+    def __getitem__(self, idx):
+        if not (-len(self) <= idx < len(self)):
+            raise IndexError(f"index {idx} is out of range")
+        if idx < 0:
+            idx += len(self)
+        it = iter(self._modules.values())
+        for _ in range(idx):
+            next(it)
+        return next(it)
+
+    def __len__(self):
+        return len(self._modules)
+
+    def __iter__(self):
+        return iter(self._modules.values())
+
+    def add(self, module, name=None):
+        if name is None:
+            name = str(len(self._modules))
+            if name in self._modules:
+                raise KeyError("name exists")
+        self.add_module(name, module)
+
+    def _fusable(self, mods, i):
+        """(n_consumed, bn, relu) for a conv at mods[i] followed by eval BN and/or ReLU."""
+        bn, relu = None, False
+        j = i + 1
+        if j < len(mods) and isinstance(mods[j], nn.BatchNorm1d) and not mods[j].training \
+                and mods[j].track_running_stats and mods[j].running_mean is not None:
+            bn = mods[j]
+            j += 1
+        if j < len(mods) and isinstance(mods[j], nn.ReLU):
+            relu = True
+            j += 1
+        return j - i, bn, relu
+
+    def forward(self, input):
+        mods = list(self._modules.values())
+        fuse = (self.fuse_inference and not torch.is_grad_enabled()
+                and isinstance(input, SparseConvTensor) and input.features.is_cuda)
+        i = 0
+        while i < len(mods):
+            module = mods[i]
+            if fuse and is_sparse_conv(module) and isinstance(input, SparseConvTensor):
+                n, bn, relu = self._fusable(mods, i)
+                if n > 1:
+                    scale = shift = None
+                    if bn is not None:
+                        scale, shift = _bn_affine(bn)
+                    input = module(input, _scale=scale, _shift=shift, _relu=relu)
+                    i += n
+                    continue
+            if is_spconv_module(module):
+                input = module(input)
+            elif isinstance(input, SparseConvTensor):
+                if input.indices.shape[0] != 0:
+                    input.features = module(input.features)
+            else:
+                input = module(input)
+            i += 1
+        return input
+
+
+class ToDense(SparseModule):
+    def forward(self, x: SparseConvTensor):
+        return x.dense()

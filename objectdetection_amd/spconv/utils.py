@@ -1,0 +1,134 @@
+"""spconv.utils: VoxelGeneratorV2 (second/builder/voxel_builder.py:23-33; used at
+second/data/preprocess.py:621-639, second/pytorch/train.py:60,
+second/pytorch/builder/second_builder.py:30-31, second/pytorch/models/voxelnet.py:147-148) and
+the import-time names of the IoU/NMS helpers (out of scope: post-processing)."""
+import numpy as np
+import torch
+
+from .. import ops
+
+
+def _out_of_scope(name):
+    def fn(*a, **k):
+        raise NotImplementedError(
+            f"spconv.utils.{name} is post-processing, outside the sparse front end "
+            "(SURVEY.md section 2); it is exported only so that imports succeed")
+    fn.__name__ = name
+    return fn
+
+
+rbbox_iou = _out_of_scope("rbbox_iou")
+rbbox_intersection = _out_of_scope("rbbox_intersection")
+non_max_suppression = _out_of_scope("non_max_suppression")
+non_max_suppression_cpu = _out_of_scope("non_max_suppression_cpu")
+rotate_non_max_suppression_cpu = _out_of_scope("rotate_non_max_suppression_cpu")
+
+
+class VoxelGeneratorV2:
+    """GPU voxel generator with the reference's constructor and result contract.
+
+    ``generate(points, max_voxels)`` takes a host ``np.ndarray [N,F] float32`` like the
+    reference's data pipeline does and returns host arrays sliced to ``voxel_num``;
+    ``generate_multi_gpu`` returns arrays padded to ``max_voxels``; ``generate_device`` takes and
+    returns GPU tensors (no host round trip) for callers that keep the cloud on the device.
+
+    ``cap_mode``: 0 = stop at the first point that would open voxel number ``max_voxels`` (the
+    numba ``points_to_voxel`` twin's ``break``, second/utils/simplevis.py:47-48; default),
+    1 = spconv's C++ behaviour (skip that point, later points still join existing voxels).
+    """
+
+    def __init__(self, voxel_size, point_cloud_range, max_num_points, max_voxels=20000,
+                 full_mean=False, block_filtering=False, block_factor=8, block_size=3,
+                 height_threshold=0.1, height_high_threshold=2.0, cap_mode=0, device=None):
+        if block_filtering:
+            raise NotImplementedError(
+                "block_filtering is not used by any shipped config (voxel_generator.proto:10 "
+                "defaults to false) and is not implemented")
+        point_cloud_range = np.array(point_cloud_range, dtype=np.float32)
+        voxel_size = np.array(voxel_size, dtype=np.float32)
+        grid_size = (point_cloud_range[3:] - point_cloud_range[:3]) / voxel_size
+        grid_size = np.round(grid_size).astype(np.int64)
+        self._voxel_size = voxel_size
+        self._point_cloud_range = point_cloud_range
+        self._max_num_points = int(max_num_points)
+        self._max_voxels = int(max_voxels)
+        self._grid_size = grid_size
+        self._full_mean = bool(full_mean)
+        self._cap_mode = int(cap_mode)
+        self._device = device
+
+    # ---- device path
+    def generate_device(self, points, max_voxels=None):
+        """points: [N,F] float32 cuda tensor -> dict of cuda tensors padded to max_voxels, with
+        ``voxel_num`` a [1] int32 cuda tensor (no synchronisation)."""
+        mv = int(max_voxels or self._max_voxels)
+        voxels, coors, num, vnum = ops.voxelize(points, self._voxel_size, self._point_cloud_range,
+                                                self._max_num_points, mv, self._cap_mode)
+        if self._full_mean:
+            # fill the empty slots of a voxel with the mean of its points
+            n = num.clamp(min=1).view(-1, 1, 1).float()
+            mean = voxels.sum(dim=1, keepdim=True) / n
+            t = torch.arange(self._max_num_points, device=voxels.device).view(1, -1, 1)
+            empty = (t >= num.view(-1, 1, 1)) & (num.view(-1, 1, 1) > 0)
+            voxels = torch.where(empty, mean.expand_as(voxels), voxels)
+        return {"voxels": voxels, "coordinates": coors, "num_points_per_voxel": num,
+                "voxel_num": vnum}
+
+    def _dev(self):
+        if self._device is not None:
+            return torch.device(self._device)
+        if not torch.cuda.is_available():
+            raise RuntimeError("VoxelGeneratorV2 (objectdetection_amd) needs a GPU: no CPU path")
+        return torch.device("cuda", torch.cuda.current_device())
+
+    def _run(self, points, max_voxels):
+        pts = np.ascontiguousarray(points, dtype=np.float32)
+        res = self.generate_device(torch.from_numpy(pts).to(self._dev()), max_voxels)
+        k = int(res["voxel_num"].item())
+        return res, k
+
+    # ---- reference API
+    def generate(self, points, max_voxels=None):
+        res, k = self._run(points, max_voxels)
+        voxels = res["voxels"][:k].cpu().numpy()
+        coors = res["coordinates"][:k].cpu().numpy()
+        num = res["num_points_per_voxel"][:k].cpu().numpy()
+        mask = (np.arange(self._max_num_points)[None, :] < num[:, None])
+        return {"voxels": voxels, "coordinates": coors, "num_points_per_voxel": num,
+                "voxel_point_mask": mask[..., None].astype(voxels.dtype), "voxel_num": k}
+
+    def generate_multi_gpu(self, points, max_voxels=None):
+        res, k = self._run(points, max_voxels)
+        voxels = res["voxels"].cpu().numpy()
+        coors = res["coordinates"].cpu().numpy()
+        num = res["num_points_per_voxel"].cpu().numpy()
+        mask = (np.arange(self._max_num_points)[None, :] < num[:, None])
+        return {"voxels": voxels, "coordinates": coors, "num_points_per_voxel": num,
+                "voxel_point_mask": mask[..., None].astype(voxels.dtype), "voxel_num": k}
+
+    @property
+    def voxel_size(self):
+        return self._voxel_size
+
+    @property
+    def max_num_points_per_voxel(self):
+        return self._max_num_points
+
+    @property
+    def point_cloud_range(self):
+        return self._point_cloud_range
+
+    @property
+    def grid_size(self):
+        return self._grid_size
+
+
+class VoxelGenerator(VoxelGeneratorV2):
+    """spconv.utils.VoxelGenerator (v1 signature); returns the tuple form."""
+
+    def __init__(self, voxel_size, point_cloud_range, max_num_points, max_voxels=20000):
+        super().__init__(voxel_size, point_cloud_range, max_num_points, max_voxels)
+
+    def generate(self, points, max_voxels=None):
+        res = super().generate(points, max_voxels)
+        return res["voxels"], res["coordinates"], res["num_points_per_voxel"]

@@ -1,0 +1,223 @@
+"""VFE voxel encoders with the reference's class names, constructor signatures, registry and
+state_dict keys (second/pytorch/models/voxel_encoder.py), on HIP streaming kernels.
+
+In inference (eval mode, gradients off, CUDA tensors) the point-wise work between the Linear
+layers -- mean-centring + concat (:116-124), BatchNorm-affine + ReLU + max over T + repeat +
+concat + padding mask (:69-80,:126-137) and the final masked max-pool (:139) -- runs as one
+coalesced streaming kernel per stage (lcf_vfe_augment / lcf_vfe_pool); the three Linear layers
+stay plain GEMMs.  In training the same maths runs through torch ops so autograd and BatchNorm
+batch statistics behave exactly as in the reference.
+"""
+import torch
+from torch import nn
+from torch.nn import functional as F
+
+from . import ops
+
+REGISTERED_VFE_CLASSES = {}
+
+
+def register_vfe(cls, name=None):
+    global REGISTERED_VFE_CLASSES
+    if name is None:
+        name = cls.__name__
+    assert name not in REGISTERED_VFE_CLASSES, f"exist class: {REGISTERED_VFE_CLASSES}"
+    REGISTERED_VFE_CLASSES[name] = cls
+    return cls
+
+
+def get_vfe_class(name):
+    global REGISTERED_VFE_CLASSES
+    assert name in REGISTERED_VFE_CLASSES, f"available class: {REGISTERED_VFE_CLASSES}"
+    return REGISTERED_VFE_CLASSES[name]
+
+
+def get_paddings_indicator(actual_num, max_num, axis=0):
+    """mask[k, t] = actual_num[k] > t  (voxel_encoder.py:27-48)."""
+    actual_num = torch.unsqueeze(actual_num, axis + 1)
+    max_num_shape = [1] * len(actual_num.shape)
+    max_num_shape[axis + 1] = -1
+    max_num = torch.arange(max_num, dtype=torch.int, device=actual_num.device).view(max_num_shape)
+    return actual_num.int() > max_num
+
+
+class _Empty(nn.Module):
+    """torchplus.nn.Empty: identity."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__()
+
+    def forward(self, *args, **kwargs):
+        if len(args) == 1:
+            return args[0]
+        elif len(args) == 0:
+            return None
+        return args
+
+
+def _norm_linear(use_norm):
+    if use_norm:
+        return (lambda c: nn.BatchNorm1d(c, eps=1e-3, momentum=0.01),
+                lambda i, o: nn.Linear(i, o, bias=False))
+    return (lambda c: _Empty(c)), (lambda i, o: nn.Linear(i, o, bias=True))
+
+
+def _affine(norm, channels, device):
+    """Eval-mode norm as (scale, shift); identity (None, None) for Empty."""
+    if isinstance(norm, nn.BatchNorm1d):
+        inv = torch.rsqrt(norm.running_var.float() + norm.eps)
+        w = norm.weight.float() if norm.weight is not None else torch.ones_like(inv)
+        b = norm.bias.float() if norm.bias is not None else torch.zeros_like(inv)
+        scale = w * inv
+        return scale.contiguous(), (b - norm.running_mean.float() * scale).contiguous()
+    return None, None
+
+
+def _fast_path(module, *tensors):
+    return (not module.training and not torch.is_grad_enabled()
+            and all(t.is_cuda and t.dtype == torch.float32 for t in tensors))
+
+
+class VFELayer(nn.Module):
+    def __init__(self, in_channels, out_channels, use_norm=True, name='vfe'):
+        super().__init__()
+        self.name = name
+        self.units = int(out_channels / 2)
+        BatchNorm1d, Linear = _norm_linear(use_norm)
+        self.linear = Linear(in_channels, self.units)
+        self.norm = BatchNorm1d(self.units)
+
+    def forward(self, inputs):
+        # reference semantics (voxel_encoder.py:65-80); the unmasked output
+        voxel_count = inputs.shape[1]
+        x = self.linear(inputs)
+        x = self.norm(x.permute(0, 2, 1).contiguous()).permute(0, 2, 1).contiguous()
+        pointwise = F.relu(x)
+        aggregated = torch.max(pointwise, dim=1, keepdim=True)[0]
+        repeated = aggregated.repeat(1, voxel_count, 1)
+        return torch.cat([pointwise, repeated], dim=2)
+
+    def forward_masked(self, inputs, num_voxels):
+        """Inference: Linear, then one streaming kernel for BN-affine+ReLU+max+concat+mask."""
+        x = self.linear(inputs)
+        scale, shift = _affine(self.norm, self.units, x.device)
+        return ops.vfe_pool(x, num_voxels, scale, shift, 0)
+
+
+class _VFEBase(nn.Module):
+    def _augment(self, features, num_voxels):
+        points_mean = features[:, :, :3].sum(dim=1, keepdim=True) / \
+            num_voxels.type_as(features).view(-1, 1, 1)
+        features_relative = features[:, :, :3] - points_mean
+        if self._with_distance:
+            points_dist = torch.norm(features[:, :, :3], 2, 2, keepdim=True)
+            return torch.cat([features, features_relative, points_dist], dim=-1)
+        return torch.cat([features, features_relative], dim=-1)
+
+    def _forward_layers(self, layers, features, num_voxels):
+        if _fast_path(self, features) and not self._with_distance and features.shape[0] > 0:
+            x = ops.vfe_augment(features, num_voxels)
+            for vfe in layers:
+                x = vfe.forward_masked(x, num_voxels)
+            x = self.linear(x)
+            scale, shift = _affine(self.norm, x.shape[-1], x.device)
+            return ops.vfe_pool(x, num_voxels, scale, shift, 1)
+        features = self._augment(features, num_voxels)
+        voxel_count = features.shape[1]
+        mask = get_paddings_indicator(num_voxels, voxel_count, axis=0)
+        mask = torch.unsqueeze(mask, -1).type_as(features)
+        x = features
+        for vfe in layers:
+            x = vfe(x)
+            x = x * mask
+        x = self.linear(x)
+        x = self.norm(x.permute(0, 2, 1).contiguous()).permute(0, 2, 1).contiguous()
+        x = F.relu(x)
+        x = x * mask
+        return torch.max(x, dim=1)[0]
+
+
+@register_vfe
+class VoxelFeatureExtractor(_VFEBase):
+    def __init__(self, num_input_features=4, use_norm=True, num_filters=[32, 128],
+                 with_distance=False, voxel_size=(0.2, 0.2, 4),
+                 pc_range=(0, -40, -3, 70.4, 40, 1), name='VoxelFeatureExtractor'):
+        super().__init__()
+        self.name = name
+        BatchNorm1d, Linear = _norm_linear(use_norm)
+        assert len(num_filters) == 2
+        num_input_features += 3  # add mean features
+        if with_distance:
+            num_input_features += 1
+        self._with_distance = with_distance
+        self.vfe1 = VFELayer(num_input_features, num_filters[0], use_norm)
+        self.vfe2 = VFELayer(num_filters[0], num_filters[1], use_norm)
+        self.linear = Linear(num_filters[1], num_filters[1])
+        self.norm = BatchNorm1d(num_filters[1])
+
+    def forward(self, features, num_voxels, coors):
+        return self._forward_layers([self.vfe1, self.vfe2], features, num_voxels)
+
+
+@register_vfe
+class VoxelFeatureExtractorV2(_VFEBase):
+    """VoxelFeatureExtractor with arbitrary number of VFE layers (voxel_encoder.py:142-204)."""
+
+    def __init__(self, num_input_features=4, use_norm=True, num_filters=[32, 128],
+                 with_distance=False, voxel_size=(0.2, 0.2, 4),
+                 pc_range=(0, -40, -3, 70.4, 40, 1), name='VoxelFeatureExtractor'):
+        super().__init__()
+        self.name = name
+        BatchNorm1d, Linear = _norm_linear(use_norm)
+        assert len(num_filters) > 0
+        num_input_features += 3
+        if with_distance:
+            num_input_features += 1
+        self._with_distance = with_distance
+        num_filters = [num_input_features] + list(num_filters)
+        filters_pairs = [[num_filters[i], num_filters[i + 1]]
+                         for i in range(len(num_filters) - 1)]
+        self.vfe_layers = nn.ModuleList([VFELayer(i, o, use_norm) for i, o in filters_pairs])
+        self.linear = Linear(num_filters[-1], num_filters[-1])
+        self.norm = BatchNorm1d(num_filters[-1])
+
+    def forward(self, features, num_voxels, coors):
+        return self._forward_layers(list(self.vfe_layers), features, num_voxels)
+
+
+@register_vfe
+class SimpleVoxel(nn.Module):
+    def __init__(self, num_input_features=4, use_norm=True, num_filters=[32, 128],
+                 with_distance=False, voxel_size=(0.2, 0.2, 4),
+                 pc_range=(0, -40, -3, 70.4, 40, 1), name='VoxelFeatureExtractor'):
+        super().__init__()
+        self.name = name
+        self.num_input_features = num_input_features
+
+    def forward(self, features, num_voxels, coors):
+        if _fast_path(self, features) and features.shape[0] > 0:
+            return ops.vfe_mean(features, num_voxels, self.num_input_features)
+        points_mean = features[:, :, :self.num_input_features].sum(dim=1, keepdim=False) / \
+            num_voxels.type_as(features).view(-1, 1)
+        return points_mean.contiguous()
+
+
+@register_vfe
+class SimpleVoxelRadius(nn.Module):
+    """Simple voxel encoder. only keep r, z and reflection feature."""
+
+    def __init__(self, num_input_features=4, use_norm=True, num_filters=(32, 128),
+                 with_distance=False, voxel_size=(0.2, 0.2, 4),
+                 pc_range=(0, -40, -3, 70.4, 40, 1), name='SimpleVoxelRadius'):
+        super().__init__()
+        self.num_input_features = num_input_features
+        self.name = name
+
+    def forward(self, features, num_voxels, coors):
+        if _fast_path(self, features) and features.shape[0] > 0:
+            points_mean = ops.vfe_mean(features, num_voxels, self.num_input_features)
+        else:
+            points_mean = features[:, :, :self.num_input_features].sum(dim=1, keepdim=False) / \
+                num_voxels.type_as(features).view(-1, 1)
+        feature = torch.norm(points_mean[:, :2], p=2, dim=1, keepdim=True)
+        return torch.cat([feature, points_mean[:, 2:self.num_input_features]], dim=1)

@@ -1,0 +1,121 @@
+"""GPU parity: HIP rulebook builder vs the CPU oracle (bit-exact canonical pairs)."""
+import numpy as np
+import pytest
+import torch
+
+from objectdetection_amd import ops, synth
+
+pytestmark = pytest.mark.gpu
+
+FHD = [  # SpMiddleFHD rulebook chain (second/pytorch/models/middle.py:145-192)
+    ("subm", 3, 1, 0), ("conv", 3, 2, 1), ("subm", 3, 1, 0), ("conv", 3, 2, 1),
+    ("subm", 3, 1, 0), ("conv", 3, 2, [0, 1, 1]), ("subm", 3, 1, 0),
+    ("conv", [3, 1, 1], [2, 1, 1], 0)]
+
+
+def _coors(oracle, pts_list, max_voxels=40000):
+    cs = []
+    for b, pts in enumerate(pts_list):
+        _, c, _ = oracle.voxelize(pts, synth.VOXEL_SIZE, synth.PC_RANGE, 5, max_voxels)
+        cs.append(np.concatenate([np.full((c.shape[0], 1), b, np.int32), c], 1))
+    return np.ascontiguousarray(np.concatenate(cs, 0))
+
+
+def _check_chain(oracle, coors, batch, shape, dev, chain=FHD):
+    shape = list(shape)
+    for kind, ks, st, pd in chain:
+        ind = torch.from_numpy(coors).to(dev)
+        rb = ops.build_rulebook(ind, batch, shape, ks, st, pd, 1, kind == "subm")
+        gp, gn = rb.indice_pairs.cpu().numpy(), rb.indice_pair_num.cpu().numpy()
+        if kind == "subm":
+            ep, en = oracle.rulebook_subm(coors, batch, shape, ks)
+            assert np.array_equal(gn, en)
+            assert np.array_equal(gp, ep)
+            assert rb.out_shape == shape
+        else:
+            eo, ep, en, eshape = oracle.rulebook_conv(coors, batch, shape, ks, st, pd)
+            assert rb.out_shape == eshape
+            assert rb.k_out == eo.shape[0]
+            assert np.array_equal(rb.out_indices.cpu().numpy(), eo)
+            assert np.array_equal(gn, en)
+            assert np.array_equal(gp, ep)
+            coors, shape = eo, eshape
+        # neighbour tables are consistent with the pair lists
+        onb, inb = rb.out_nbr.cpu().numpy(), rb.in_nbr.cpu().numpy()
+        kvol = gn.shape[0]
+        assert (onb >= 0).sum() == gn.sum() == (inb >= 0).sum()
+        for o in range(kvol):
+            i_, o_ = gp[0, o, :gn[o]], gp[1, o, :gn[o]]
+            assert np.array_equal(onb[o_, o], i_)
+            assert np.array_equal(inb[i_, o], o_)
+    return shape
+
+
+def test_fhd_chain_vkitti(oracle, cuda):
+    coors = _coors(oracle, [synth.vkitti_frame(0, 20000)])
+    out = _check_chain(oracle, coors, 1, [41, 1600, 1408], cuda)
+    assert out == [2, 200, 176]
+
+
+def test_fhd_chain_batch2_synthia(oracle, cuda):
+    coors = _coors(oracle, [synth.synthia_frame(0, 60000), synth.vkitti_frame(1, 20000)], 200000)
+    _check_chain(oracle, coors, 2, [41, 1600, 1408], cuda)
+
+
+def test_small_random_shapes(oracle, cuda):
+    rng = np.random.default_rng(0)
+    for it in range(12):
+        shape = [int(rng.integers(3, 9)), int(rng.integers(4, 20)), int(rng.integers(4, 20))]
+        batch = int(rng.integers(1, 4))
+        n = int(rng.integers(1, 300))
+        cells = rng.integers(0, batch * shape[0] * shape[1] * shape[2], n)
+        cells = np.unique(cells)
+        rng.shuffle(cells)
+        x = cells % shape[2]
+        y = (cells // shape[2]) % shape[1]
+        z = (cells // (shape[2] * shape[1])) % shape[0]
+        b = cells // (shape[2] * shape[1] * shape[0])
+        coors = np.ascontiguousarray(np.stack([b, z, y, x], 1).astype(np.int32))
+        chain = [("subm", 3, 1, 0), ("conv", [int(rng.integers(1, 4)) for _ in range(3)],
+                                     [int(rng.integers(1, 3)) for _ in range(3)],
+                                     [int(rng.integers(0, 2)) for _ in range(3)]),
+                 ("subm", [1, 3, 3], 1, 0), ("subm", 1, 1, 0)]
+        _check_chain(oracle, coors, batch, shape, cuda, chain)
+
+
+def test_subm_dilation_and_empty(oracle, cuda):
+    coors = _coors(oracle, [synth.vkitti_frame(2, 5000)])
+    ind = torch.from_numpy(coors).to(cuda)
+    rb = ops.build_rulebook(ind, 1, [41, 1600, 1408], 3, 1, 0, 2, True)
+    ep, en = oracle.rulebook_subm(coors, 1, [41, 1600, 1408], 3, 2)
+    assert np.array_equal(rb.indice_pair_num.cpu().numpy(), en)
+    assert np.array_equal(rb.indice_pairs.cpu().numpy(), ep)
+    empty = torch.zeros((0, 4), dtype=torch.int32, device=cuda)
+    rb = ops.build_rulebook(empty, 1, [41, 1600, 1408], 3, 2, 1, 1, False)
+    assert rb.k_out == 0 and rb.indice_pair_num.sum().item() == 0
+    rb = ops.build_rulebook(empty, 1, [41, 1600, 1408], 3, 1, 0, 1, True)
+    assert rb.k_out == 0
+
+
+def test_known_answers(cuda):
+    """Hand-derived: one voxel; two x-adjacent voxels."""
+    one = torch.tensor([[0, 5, 5, 5]], dtype=torch.int32, device=cuda)
+    rb = ops.build_rulebook(one, 1, [11, 11, 11], 3, 1, 0, 1, True)
+    pn = rb.indice_pair_num.cpu().numpy()
+    assert pn.sum() == 1 and pn[13] == 1  # centre offset only
+    two = torch.tensor([[0, 5, 5, 5], [0, 5, 5, 6]], dtype=torch.int32, device=cuda)
+    rb = ops.build_rulebook(two, 1, [11, 11, 11], 3, 1, 0, 1, True)
+    pn = rb.indice_pair_num.cpu().numpy()
+    pr = rb.indice_pairs.cpu().numpy()
+    assert pn.sum() == 4 and pn[13] == 2 and pn[12] == 1 and pn[14] == 1
+    # offset 14 = (kz,ky,kx)=(1,1,2): input x = output x + 1 -> input row 1 feeds output row 0
+    assert (pr[0, 14, 0], pr[1, 14, 0]) == (1, 0)
+    assert (pr[0, 12, 0], pr[1, 12, 0]) == (0, 1)
+    # stride 2, pad 1, k 3: coordinate 5 feeds outputs 3 (k=0) and 2 (k=2), coordinate 6 feeds
+    # output 3 (k=1) only -> voxel (5,5,5) opens 2x2x2 outputs, discovered from the upper corner
+    # downward with x fastest; voxel (5,5,6) only re-uses four of them.
+    rb = ops.build_rulebook(two, 1, [11, 11, 11], 3, 2, 1, 1, False)
+    assert rb.out_shape == [6, 6, 6] and rb.k_out == 8
+    assert rb.out_indices.cpu().tolist()[:4] == [[0, 3, 3, 3], [0, 3, 3, 2], [0, 3, 2, 3],
+                                                 [0, 3, 2, 2]]
+    assert rb.indice_pair_num.sum().item() == 12
