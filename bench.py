@@ -1,0 +1,168 @@
+#!/usr/bin/env python3
+"""bench.py -- frames/s of the SECOND sparse front end (voxelize + VFE + sparse middle forward,
+batch 1) on MI355X, with the dominant kernel's roofline fraction and a same-host CPU baseline.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--model M1|M2|M3]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" = one frame through the whole hot path (BASELINE.json configs[1]: one ~20k-point
+Virtual-KITTI-shaped frame on the 1600x1408x41 grid, fp32) with the point cloud already resident
+in HBM.  N > 1 runs one replica per GPU on its own frames (scene sharding, no data-path
+collective; SURVEY.md section 8e: "inference: replicas only") and reports the whole-job rate.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from objectdetection_amd import ops, synth  # noqa: E402
+from objectdetection_amd.frontend import SparseFrontEnd, randomize_  # noqa: E402
+
+F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md "Peak FP32 (matrix)"
+
+
+def dominant_kernel_roofline(model, cloud, reps=20):
+    """Times every launch of the dominant kernel -- cv_fwd_kernel<64,64>, the 64->64 channel
+    indice_conv (fused gather-GEMM-scatter + BN + ReLU) -- with HIP events on the stream it is
+    launched on, after the timed region.  achieved = algorithmic flops per launch
+    (2 * pairs * Cin * Cout) / average launch duration."""
+    from objectdetection_amd.spconv import SparseConvTensor
+    from objectdetection_amd.spconv.modules import _bn_affine
+    mid = model.middle_feature_extractor
+    voxels, num, coors = model.voxelize([cloud])
+    feats = model.voxel_feature_extractor(voxels, num, coors)
+    x = SparseConvTensor(feats, coors, mid.sparse_shape, 1)
+    mods = list(mid.middle_conv)
+    launches = []
+    i = 0
+    while i < len(mods):
+        conv, bn = mods[i], mods[i + 1]
+        rb = conv.get_rulebook(x)
+        scale, shift = _bn_affine(bn)
+        args = (x.features, conv._weight_image(), rb.out_nbr, rb.k_out, rb.kvol,
+                conv.in_channels, conv.out_channels, scale, shift, True)
+        if conv.in_channels == 64 and conv.out_channels == 64:
+            pairs = int((rb.out_nbr >= 0).sum().item())
+            launches.append((args, pairs, rb.k_in, rb.k_out))
+        x = conv(x, _scale=scale, _shift=shift, _relu=True)
+        i += 3
+    torch.cuda.synchronize()
+    total_ms, total_flops, n = 0.0, 0.0, 0
+    stream = torch.cuda.current_stream()
+    for args, pairs, _, _ in launches:
+        ops.conv_forward(*args)  # warm
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(reps):
+            ops.conv_forward(*args)
+        e1.record(stream)
+        e1.synchronize()
+        total_ms += e0.elapsed_time(e1) / reps
+        total_flops += 2.0 * pairs * 64 * 64
+        n += 1
+    avg_s = total_ms / n * 1e-3
+    achieved = total_flops / n / avg_s / 1e12
+    return {"bound": "mfma", "achieved": round(achieved, 3), "peak": F32_MFMA_PEAK_TFLOPS,
+            "unit": "TFLOP/s", "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+            "kernel": "cv_fwd_kernel<64,64>", "launches_per_frame": n,
+            "avg_launch_us": round(avg_s * 1e6, 2),
+            "flops_per_launch": round(total_flops / n, 0)}
+
+
+def cpu_baseline(model_name, cloud_np, budget_s):
+    from oracle import cpu_pipeline  # the CPU restatement: baseline only, never the product
+    m = randomize_(SparseFrontEnd(model_name).eval(), 0)
+    fps, iters, threads, times = cpu_pipeline.time_frontend(m, [cloud_np], budget_s=budget_s)
+    return {"value": round(fps, 3), "unit": "frames/s", "cores": threads, "kind": "port",
+            "host_cpus": os.cpu_count(),
+            "sample": f"{iters} timed passes of the same N={cloud_np.shape[0]} frame (seed 0) "
+                      f"through oracle/cpu_pipeline.py after 1 warm-up; median "
+                      f"{np.median(times) * 1e3:.0f} ms/frame; restatement of numba "
+                      f"points_to_voxel (1 thread) + spconv CPU indice_conv (torch.mm, "
+                      f"{threads} threads), not the original binaries"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--model", default="M2", choices=["M1", "M2", "M3"])
+    ap.add_argument("--points", type=int, default=20000)
+    ap.add_argument("--frames", type=int, default=8, help="distinct synthetic frames cycled")
+    ap.add_argument("--cpu-budget", type=float, default=15.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    model = randomize_(SparseFrontEnd(args.model).eval(), 0).to(dev)
+    # each rank owns its own scenes (scene sharding): seeds rank*frames ... rank*frames+frames-1
+    clouds_np = [synth.vkitti_frame(rank * args.frames + i, args.points)
+                 for i in range(args.frames)]
+    clouds = [torch.from_numpy(c).to(dev) for c in clouds_np]  # resident in HBM before timing
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for i in range(args.warmup):
+            out = model([clouds[i % len(clouds)]])
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            out = model([clouds[i % len(clouds)]])
+        barrier()
+        elapsed = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        assert out.shape[1:] == (128, 200, 176) or args.model == "M3", out.shape
+        roof = dominant_kernel_roofline(model, clouds[0]) if rank == 0 and args.model != "M3" \
+            else None
+
+    if rank == 0:
+        fps = world * args.steps / elapsed
+        line = {
+            "metric": "frames/s voxelize+sparse backbone fwd (bs1)",
+            "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"{args.model}: one {args.points}-point Virtual-KITTI-shaped "
+                                   "frame per step, 1600x1408x41 grid (0.05/0.05/0.1 m, T=5), "
+                                   "voxelize + VFE + SpMiddleFHD forward + dense(), batch 1 "
+                                   "(BASELINE.json configs[1])",
+                       "model": args.model, "points_per_frame": args.points,
+                       "parallelism": f"replicas x{world} (scene-sharded, no collective)"},
+        }
+        if roof is not None:
+            line["roofline"] = roof
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.model, clouds_np[0], args.cpu_budget)
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
