@@ -1,0 +1,68 @@
+"""CPU, world_size 2 over gloo: the scene-sharded gradient exchange (one flat all-reduce)."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from objectdetection_amd.dist import FlatGradAllReduce, shard_scenes
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.ReLU(), torch.nn.Linear(16, 4))
+    bucket = FlatGradAllReduce(model.parameters())
+    data = torch.arange(4 * 8, dtype=torch.float32).view(4, 8) / 10
+    shards = shard_scenes([3, 1, 2, 2], world)
+    bucket.zero()
+    x = data[shards[rank]]
+    (model(x) ** 2).sum().backward()
+    # per-rank loss is a SUM over its scenes; the exchange averages over ranks
+    bucket.reduce()
+    q.put((rank, shards, bucket.flat.clone()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_flat_allreduce_equals_single_process_average():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    res.sort(key=lambda t: t[0])
+    assert torch.equal(res[0][2], res[1][2])  # every rank holds the same averaged gradient
+    shards = res[0][1]
+    assert sorted(sum(shards, [])) == [0, 1, 2, 3]
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.ReLU(), torch.nn.Linear(16, 4))
+    data = torch.arange(4 * 8, dtype=torch.float32).view(4, 8) / 10
+    (model(data) ** 2).sum().backward()
+    ref = torch.cat([p.grad.flatten() for p in model.parameters()]) / world
+    assert torch.allclose(res[0][2], ref, rtol=1e-5, atol=1e-6)
+
+
+def test_shard_scenes_balances_cost():
+    costs = [120, 20, 20, 20, 20, 20, 20, 20]
+    shards = shard_scenes(costs, 2)
+    loads = [sum(costs[i] for i in s) for s in shards]
+    assert sorted(sum(shards, [])) == list(range(8))
+    assert max(loads) - min(loads) <= 20
+    assert shard_scenes([1, 1, 1, 1], 4) == [[0], [1], [2], [3]]
+    assert [len(s) for s in shard_scenes([5] * 64, 8)] == [8] * 8

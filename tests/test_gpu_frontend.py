@@ -126,3 +126,24 @@ def test_vfe_kernels_match_torch(cuda):
             got = m.to(cuda)(vox.to(cuda), num.to(cuda), None).cpu().numpy()  # HIP kernels
         assert got.shape == ref.shape
         assert rel_err(got, ref) < 1e-5, cls.__name__
+
+
+def test_vfe_hip_path_matches_reference_golden(cuda):
+    """HIP streaming VFE path vs vectors captured from the real reference file."""
+    import os
+    from objectdetection_amd import voxel_encoder as ve
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "vfe_golden.npz"))
+    vox = torch.from_numpy(G["voxels"]).to(cuda)
+    num = torch.from_numpy(G["num_points"]).to(cuda)
+    for tag, kw in [("SimpleVoxel", {}), ("SimpleVoxelRadius", {}),
+                    ("VoxelFeatureExtractor", dict(num_filters=[32, 128])),
+                    ("VoxelFeatureExtractorV2", dict(num_filters=[16, 32, 64])),
+                    ("VoxelFeatureExtractor_nonorm", dict(num_filters=[32, 128], use_norm=False))]:
+        m = ve.get_vfe_class(tag.split("_")[0])(num_input_features=4, **kw)
+        pre = tag + "/param/"
+        m.load_state_dict({k[len(pre):]: torch.from_numpy(G[k].copy()) for k in G.files
+                           if k.startswith(pre)}, strict=True)
+        m = m.to(cuda).eval()
+        with torch.no_grad():
+            got = m(vox, num, None).cpu().numpy()
+        assert rel_err(got, G[f"{tag}/eval"]) < 2e-5, tag
