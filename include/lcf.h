@@ -38,6 +38,12 @@ extern "C" {
 const char *lcf_strerror(int rc);
 int lcf_version(void);
 
+/* Process-wide tuning options (no counterpart in the reference).
+ * LCF_OPT_CONV_SPLIT: how many waves share one 16-row tile of the indice_conv forward by
+ * splitting its output columns: 1, 2 or 4; 0 (default) = choose from the row count. */
+#define LCF_OPT_CONV_SPLIT 0
+int lcf_set_option(int option, int value);
+
 /* ------------------------------------------------------------------------------------------
  * Voxelization.
  * Replaces: spconv.utils.VoxelGeneratorV2.generate / generate_multi_gpu

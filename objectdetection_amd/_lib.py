@@ -20,6 +20,7 @@ _PF = ctypes.POINTER(ctypes.c_float)
 SYMBOLS = {
     "lcf_strerror": (ctypes.c_char_p, [c_int]),
     "lcf_version": (c_int, []),
+    "lcf_set_option": (c_int, [c_int, c_int]),
     "lcf_voxelize_workspace_bytes": (c_size_t, [c_int, c_int]),
     "lcf_voxelize": (c_int, [c_void_p, c_int, c_int, _PF, _PF, c_int, c_int, c_int, c_void_p,
                              c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),

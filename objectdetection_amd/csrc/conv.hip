@@ -11,6 +11,8 @@
 // is the tile's own store, so there are no atomics and the result is run-to-run deterministic.
 // v_mfma_f32_16x16x4_f32 is an exact fp32 FMA chain (MI355X guide section 3), so results agree
 // with the CPU oracle to fp32 summation-order differences (<= 1e-4 relative is the test bar).
+#include <stdlib.h>
+
 #include "common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -70,11 +72,10 @@ cv_weight_image_kernel(const float *__restrict__ w, int kvol, int cin, int cout,
     }
 }
 
-template <int KL> struct AVec;
-template <> struct AVec<1> { typedef float T; };
-template <> struct AVec<2> { typedef float2 T; };
-
-template <int CIN, int COUT>
+// NSPLIT = how many waves share one 16-row tile by splitting its output columns.  More splits
+// = smaller workgroups (16*4/NSPLIT rows) = finer load balance over the 256 CUs when K is only a
+// few tens of thousands of rows, at the price of re-staging W[o] for fewer rows.
+template <int CIN, int COUT, int NSPLIT>
 __global__ void __launch_bounds__(CV_BLOCK)
 cv_fwd_kernel(const float *__restrict__ feat, const float *__restrict__ wimg,
               const int *__restrict__ nbr, int k_out, int kvol, int cin, int cout,
@@ -84,27 +85,34 @@ cv_fwd_kernel(const float *__restrict__ feat, const float *__restrict__ wimg,
     constexpr int KL = CIN / 4;          // k values per lane quarter
     constexpr int VW = KL < 4 ? KL : 4;  // floats per LDS fragment read
     constexpr int SG = KL / VW;          // fragment reads per column tile
-    constexpr int NT = COUT / 16;        // column tiles
+    constexpr int NT = COUT / 16 / NSPLIT; // column tiles per wave
+    constexpr int RT = CV_WAVES / NSPLIT;  // row tiles per workgroup
+    constexpr int ROWS = RT * 16;          // rows per workgroup
     constexpr int WELEMS = CIN * COUT;   // floats per offset image
     constexpr int WVEC = WELEMS / 4;     // float4 per offset image
     constexpr int WPT = (WVEC + CV_BLOCK - 1) / CV_BLOCK; // float4 per thread to stage
+    constexpr bool WFULL = (WVEC % CV_BLOCK) == 0;
+    constexpr int A4 = KL >= 4 ? KL / 4 : 1; // float4 registers of A per lane
+    static_assert(NT >= 1 && RT >= 1, "bad split");
 
     extern __shared__ __align__(16) unsigned char smem[];
     float *wl = reinterpret_cast<float *>(smem);                 // [2][WELEMS]
-    int *nl = reinterpret_cast<int *>(smem + 2 * WELEMS * 4);    // [CV_ROWS][kvol]
-    int *act = nl + CV_ROWS * kvol;                              // [kvol] active offsets
+    int *nl = reinterpret_cast<int *>(smem + 2 * WELEMS * 4);    // [ROWS][kvol]
+    int *act = nl + ROWS * kvol;                                 // [kvol] active offsets
     int *nact_p = act + kvol;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
+    const int rt = wave / NSPLIT;        // row tile of this wave
+    const int cs = wave % NSPLIT;        // column slice of this wave
     const int r16 = lane & 15;
     const int q = lane >> 4;
-    const int row0 = blockIdx.x * CV_ROWS;
+    const int row0 = blockIdx.x * ROWS;
 
     // ---- neighbour tile -> LDS (coalesced), rows past k_out read as -1
     {
-        const int total = CV_ROWS * kvol;
+        const int total = ROWS * kvol;
         const long long gbase = (long long)row0 * kvol;
         const long long glimit = (long long)k_out * kvol;
         for (int e = tid; e < total; e += CV_BLOCK)
@@ -115,7 +123,7 @@ cv_fwd_kernel(const float *__restrict__ feat, const float *__restrict__ wimg,
     if (wave == 0) {
         bool any = false;
         if (lane < kvol) {
-            for (int r = 0; r < CV_ROWS; ++r) any |= nl[r * kvol + lane] >= 0;
+            for (int r = 0; r < ROWS; ++r) any |= nl[r * kvol + lane] >= 0;
         }
         unsigned long long m = __ballot(any);
         if (lane == 0) {
@@ -136,133 +144,146 @@ cv_fwd_kernel(const float *__restrict__ feat, const float *__restrict__ wimg,
     for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const bool exact = (cin == CIN);
-    const int myrow = wave * CV_ROWS_PER_WAVE + r16;
+    const int myrow = rt * 16 + r16;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
 
-    auto gather = [&](int o, float(&a)[KL]) -> bool {
+    // A operand of one offset: KL floats per lane (k = q*KL .. q*KL+KL-1 of the gathered row)
+    struct AFrag { float4 v[A4]; };
+
+    auto gather = [&](int o, bool &any) -> AFrag {
+        AFrag a;
         int id = nl[myrow * kvol + o];
         bool has = id >= 0;
+#pragma unroll
+        for (int i = 0; i < A4; ++i) a.v[i] = zero4;
         if (has) {
             const float *src = feat + (size_t)id * cin + q * KL;
             if (exact) {
                 if constexpr (KL >= 4) {
 #pragma unroll
-                    for (int v = 0; v < KL / 4; ++v) {
-                        float4 x = reinterpret_cast<const float4 *>(src)[v];
-                        a[4 * v + 0] = x.x;
-                        a[4 * v + 1] = x.y;
-                        a[4 * v + 2] = x.z;
-                        a[4 * v + 3] = x.w;
-                    }
+                    for (int i = 0; i < A4; ++i) a.v[i] = reinterpret_cast<const float4 *>(src)[i];
                 } else if constexpr (KL == 2) {
                     float2 x = *reinterpret_cast<const float2 *>(src);
-                    a[0] = x.x;
-                    a[1] = x.y;
+                    a.v[0].x = x.x;
+                    a.v[0].y = x.y;
                 } else {
-                    a[0] = src[0];
+                    a.v[0].x = src[0];
                 }
             } else {
+                float tmp[A4 * 4];
 #pragma unroll
-                for (int s = 0; s < KL; ++s) a[s] = (q * KL + s < cin) ? src[s] : 0.f;
+                for (int s = 0; s < A4 * 4; ++s)
+                    tmp[s] = (s < KL && q * KL + s < cin) ? src[s] : 0.f;
+#pragma unroll
+                for (int i = 0; i < A4; ++i)
+                    a.v[i] = make_float4(tmp[4 * i], tmp[4 * i + 1], tmp[4 * i + 2], tmp[4 * i + 3]);
             }
-        } else {
-#pragma unroll
-            for (int s = 0; s < KL; ++s) a[s] = 0.f;
         }
-        return __ballot(has) != 0ull; // wave-uniform: does this 16-row tile touch offset o?
+        any = __ballot(has) != 0ull; // wave-uniform: does this 16-row tile touch offset o?
+        return a;
     };
 
-    float4 wreg[WPT];
-    auto wload = [&](int o) {
+    struct WFrag { float4 v[WPT]; };
+    auto wload = [&](int o) -> WFrag {
+        WFrag w;
         const float4 *src = reinterpret_cast<const float4 *>(wimg + (size_t)o * WELEMS);
 #pragma unroll
         for (int i = 0; i < WPT; ++i) {
-            int e = tid + i * CV_BLOCK;
-            if (e < WVEC) wreg[i] = src[e];
+            if constexpr (WFULL) {
+                w.v[i] = src[tid + i * CV_BLOCK];
+            } else {
+                int e = tid + i * CV_BLOCK;
+                w.v[i] = src[e < WVEC ? e : 0];
+            }
         }
+        return w;
     };
-    auto wstore = [&](int buf) {
+    auto wstore = [&](int buf, const WFrag &w) {
         float4 *dst = reinterpret_cast<float4 *>(wl + buf * WELEMS);
 #pragma unroll
         for (int i = 0; i < WPT; ++i) {
-            int e = tid + i * CV_BLOCK;
-            if (e < WVEC) dst[e] = wreg[i];
+            if constexpr (WFULL) {
+                dst[tid + i * CV_BLOCK] = w.v[i];
+            } else {
+                int e = tid + i * CV_BLOCK;
+                if (e < WVEC) dst[e] = w.v[i];
+            }
         }
     };
-    auto compute = [&](int buf, const float(&a)[KL]) {
+    auto afloat = [&](const AFrag &a, int s) -> float {
+        const float4 x = a.v[s >> 2];
+        switch (s & 3) {
+        case 0: return x.x;
+        case 1: return x.y;
+        case 2: return x.z;
+        default: return x.w;
+        }
+    };
+    auto compute = [&](int buf, const AFrag &a) {
         const float *wb = wl + buf * WELEMS;
 #pragma unroll
         for (int sg = 0; sg < SG; ++sg) {
+            float b[NT][VW];
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                const float *p = wb + (((t * SG + sg) * 4 + q) * 16 + r16) * VW;
-                float b[VW];
+                const int tg = cs * NT + t;
+                const float *p = wb + (((tg * SG + sg) * 4 + q) * 16 + r16) * VW;
                 if constexpr (VW == 4) {
                     float4 x = *reinterpret_cast<const float4 *>(p);
-                    b[0] = x.x;
-                    b[1] = x.y;
-                    b[2] = x.z;
-                    b[3] = x.w;
+                    b[t][0] = x.x;
+                    b[t][1] = x.y;
+                    b[t][2] = x.z;
+                    b[t][3] = x.w;
                 } else if constexpr (VW == 2) {
                     float2 x = *reinterpret_cast<const float2 *>(p);
-                    b[0] = x.x;
-                    b[1] = x.y;
+                    b[t][0] = x.x;
+                    b[t][1] = x.y;
                 } else {
-                    b[0] = p[0];
+                    b[t][0] = p[0];
                 }
-#pragma unroll
-                for (int v = 0; v < VW; ++v)
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[sg * VW + v], b[v], acc[t], 0,
-                                                                  0, 0);
             }
+            // k-step outer, column tile inner: consecutive MFMAs hit different accumulators
+#pragma unroll
+            for (int v = 0; v < VW; ++v)
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(afloat(a, sg * VW + v), b[t][v],
+                                                                  acc[t], 0, 0, 0);
         }
     };
 
-    float a0[KL], a1[KL];
-    bool h0 = false, h1 = false;
-    if (nact > 0) {
-        wload(act[0]);
-        h0 = gather(act[0], a0);
-        wstore(0);
-    }
-    __syncthreads();
-
-    // two offsets per trip so the A register sets keep static names
-    for (int idx = 0; idx < nact; idx += 2) {
-        // ---- even step: compute with a0 / buf 0, prefetch into a1 / buf 1
-        {
-            const bool more = idx + 1 < nact;
-            if (more) {
-                wload(act[idx + 1]);
-                h1 = gather(act[idx + 1], a1);
-            }
-            if (h0) compute(0, a0);
-            if (more) wstore(1);
+    if (nact == 0) goto epilogue_;
+    {
+        bool hcur = false, hnext = false;
+        WFrag w = wload(act[0]);
+        AFrag acur = gather(act[0], hcur);
+        wstore(0, w);
+        __syncthreads();
+        // Offset idx is computed from LDS buffer idx&1 while W / A of offset idx+1 are in
+        // flight to registers; they land in the other buffer before the (single) barrier.
+        for (int idx = 0; idx < nact; ++idx) {
+            const int nxt = act[idx + 1 < nact ? idx + 1 : idx]; // clamped: last trip reloads
+            w = wload(nxt);
+            AFrag anext = gather(nxt, hnext);
+            if (hcur) compute(idx & 1, acur);
+            wstore((idx + 1) & 1, w);
             __syncthreads();
-        }
-        if (idx + 1 >= nact) break;
-        // ---- odd step
-        {
-            const bool more = idx + 2 < nact;
-            if (more) {
-                wload(act[idx + 2]);
-                h0 = gather(act[idx + 2], a0);
-            }
-            if (h1) compute(1, a1);
-            if (more) wstore(0);
-            __syncthreads();
+            acur = anext;
+            hcur = hnext;
         }
     }
+epilogue_:
 
     // ---- epilogue: (acc * scale + shift), relu, store.  C/D map: col = lane&15, row = q*4+reg
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        const int col = t * 16 + r16;
+        const int col = (cs * NT + t) * 16 + r16;
         if (col < cout) {
             const float sc = scale ? scale[col] : 1.f;
             const float sh = shift ? shift[col] : 0.f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int row = row0 + wave * CV_ROWS_PER_WAVE + q * 4 + r;
+                const int row = row0 + rt * 16 + q * 4 + r;
                 if (row < k_out) {
                     float v = acc[t][r];
                     if (scale) v = v * sc;
@@ -365,24 +386,65 @@ extern "C" int lcf_weight_image(const float *w, int kvol, int cin, int cout, int
     return LCF_OK;
 }
 
+template <int CIN, int COUT, int NSPLIT>
+static int cv_launch_fwd_n(const float *feat, const float *wimg, const int *nbr, int k_out,
+                           int kvol, int cin, int cout, const float *scale, const float *shift,
+                           int relu, float *out, hipStream_t st)
+{
+    constexpr int ROWS = 16 * CV_WAVES / NSPLIT;
+    size_t lds = (size_t)2 * CIN * COUT * 4 + (size_t)ROWS * kvol * 4 + (size_t)kvol * 4 + 16;
+    int nb = (k_out + ROWS - 1) / ROWS;
+    if (lds > 64 * 1024) {
+        // more than the 64 KiB default: opt in (gfx950 has 160 KiB of LDS per CU)
+        if (hipFuncSetAttribute((const void *)cv_fwd_kernel<CIN, COUT, NSPLIT>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds) != hipSuccess)
+            return LCF_ERR_LAUNCH;
+    }
+    cv_fwd_kernel<CIN, COUT, NSPLIT><<<nb, CV_BLOCK, lds, st>>>(feat, wimg, nbr, k_out, kvol, cin,
+                                                                cout, scale, shift, relu, out);
+    LCF_CHECK_LAUNCH();
+    return LCF_OK;
+}
+
+// Tuning knob (lcf_set_option(LCF_OPT_CONV_SPLIT, 1|2|4)); 0 = pick by size.
+static int g_conv_split = 0;
+static int cv_split_override() { return g_conv_split; }
+
+extern "C" int lcf_set_option(int option, int value)
+{
+    if (option == LCF_OPT_CONV_SPLIT) {
+        if (value != 0 && value != 1 && value != 2 && value != 4) return LCF_ERR_ARG;
+        g_conv_split = value;
+        return LCF_OK;
+    }
+    return LCF_ERR_ARG;
+}
+
 template <int CIN, int COUT>
 static int cv_launch_fwd(const float *feat, const float *wimg, const int *nbr, int k_out,
                          int kvol, int cin, int cout, const float *scale, const float *shift,
                          int relu, float *out, hipStream_t st)
 {
-    size_t lds = (size_t)2 * CIN * COUT * 4 + (size_t)CV_ROWS * kvol * 4 + (size_t)kvol * 4 + 16;
-    int nb = (k_out + CV_ROWS - 1) / CV_ROWS;
-    if (lds > 64 * 1024) {
-        // more than the 64 KiB default: opt in (gfx950 has 160 KiB of LDS per CU)
-        if (hipFuncSetAttribute((const void *)cv_fwd_kernel<CIN, COUT>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds) != hipSuccess)
-            return LCF_ERR_LAUNCH;
+    // Smaller workgroups while the launch would otherwise leave CUs unevenly loaded: aim for
+    // >= ~4 workgroups per CU (256 CUs).
+    int split = 1;
+    constexpr int MAXSPLIT = COUT / 16 >= 4 ? 4 : COUT / 16;
+    while (split < MAXSPLIT && (long long)k_out * split < 64ll * 256 * 4) split *= 2;
+    int ov = cv_split_override();
+    if (ov == 1 || ov == 2 || ov == 4) split = ov <= MAXSPLIT ? ov : MAXSPLIT;
+    if constexpr (MAXSPLIT >= 4) {
+        if (split == 4)
+            return cv_launch_fwd_n<CIN, COUT, 4>(feat, wimg, nbr, k_out, kvol, cin, cout, scale,
+                                                 shift, relu, out, st);
     }
-    cv_fwd_kernel<CIN, COUT><<<nb, CV_BLOCK, lds, st>>>(feat, wimg, nbr, k_out, kvol, cin, cout,
-                                                        scale, shift, relu, out);
-    LCF_CHECK_LAUNCH();
-    return LCF_OK;
+    if constexpr (MAXSPLIT >= 2) {
+        if (split == 2)
+            return cv_launch_fwd_n<CIN, COUT, 2>(feat, wimg, nbr, k_out, kvol, cin, cout, scale,
+                                                 shift, relu, out, st);
+    }
+    return cv_launch_fwd_n<CIN, COUT, 1>(feat, wimg, nbr, k_out, kvol, cin, cout, scale, shift,
+                                         relu, out, st);
 }
 
 #define CV_DISPATCH(FN, ...)                                                          \

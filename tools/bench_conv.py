@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""Per-layer timing of the indice_conv forward on the real rulebooks of one synthetic frame.
+Interleaved rounds in one process (MI355X guide rule 24).  Usage: python tools/bench_conv.py"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from objectdetection_amd import _lib, ops, synth  # noqa: E402
+from objectdetection_amd.frontend import SparseFrontEnd, randomize_  # noqa: E402
+from objectdetection_amd.spconv import SparseConvTensor  # noqa: E402
+from objectdetection_amd.spconv.modules import _bn_affine  # noqa: E402
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
+    dev = torch.device("cuda:0")
+    model = randomize_(SparseFrontEnd("M2").eval(), 0).to(dev)
+    cloud = torch.from_numpy(synth.vkitti_frame(0, n) if n <= 40000 else
+                             synth.synthia_frame(0, n)).to(dev)
+    L = _lib.lib()
+    layers = []
+    with torch.no_grad():
+        voxels, num, coors = model.voxelize([cloud])
+        feats = model.voxel_feature_extractor(voxels, num, coors)
+        mid = model.middle_feature_extractor
+        x = SparseConvTensor(feats, coors, mid.sparse_shape, 1)
+        mods = list(mid.middle_conv)
+        for i in range(0, len(mods), 3):
+            conv, bn = mods[i], mods[i + 1]
+            rb = conv.get_rulebook(x)
+            scale, shift = _bn_affine(bn)
+            args = (x.features, conv._weight_image(), rb.out_nbr, rb.k_out, rb.kvol,
+                    conv.in_channels, conv.out_channels, scale, shift, True)
+            pairs = int((rb.out_nbr >= 0).sum().item())
+            layers.append((f"{'subm' if conv.subm else 'conv'} {conv.in_channels}->"
+                           f"{conv.out_channels} K={rb.k_out}", args, pairs))
+            x = conv(x, _scale=scale, _shift=shift, _relu=True)
+    torch.cuda.synchronize()
+    reps, rounds = 10, 5
+    splits = [0, 1, 2, 4]
+    res = {}
+    for r in range(rounds):
+        for sp in splits:
+            L.lcf_set_option(0, sp)
+            for li, (name, args, pairs) in enumerate(layers):
+                ops.conv_forward(*args)
+                e0 = torch.cuda.Event(enable_timing=True)
+                e1 = torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(reps):
+                    ops.conv_forward(*args)
+                e1.record()
+                e1.synchronize()
+                res.setdefault((li, sp), []).append(e0.elapsed_time(e1) / reps * 1e3)
+    L.lcf_set_option(0, 0)
+    tot = {sp: 0.0 for sp in splits}
+    print(f"{'layer':34s} {'pairs':>8s} " + " ".join(f"split{sp}:us/TF" .rjust(16) for sp in splits))
+    for li, (name, args, pairs) in enumerate(layers):
+        cin, cout = args[5], args[6]
+        row = f"{name:34s} {pairs:8d} "
+        for sp in splits:
+            us = min(res[(li, sp)])
+            tot[sp] += us
+            row += f"{us:9.1f}/{2.0 * pairs * cin * cout / us / 1e6:5.1f} "
+        print(row)
+    print("total us:", {sp: round(v, 1) for sp, v in tot.items()})
+
+
+if __name__ == "__main__":
+    main()
