@@ -11,6 +11,10 @@
  *   - Return 0 on success, a negative LCF_ERR_* otherwise; lcf_strerror() names it.
  *   - Data-dependent sizes (number of voxels, number of active outputs) come back through
  *     device int32 scalars; the caller passes capacities.
+ *   - Row counts go IN as a pair (int k, const int *k_dev).  With k_dev == NULL, k is the count.
+ *     With k_dev != NULL the kernels read the count from device memory, clamped to k, which is
+ *     then the CAPACITY of the buffers; launch geometry depends on k only.  A whole frame can
+ *     therefore be enqueued (or captured into a hipGraph) without one host synchronisation.
  *
  * The reference binds this path through the third-party `spconv` python package (1.x, not
  * vendored, README.md:29) and a numba kernel; each entry point below names the reference
@@ -42,6 +46,9 @@ int lcf_version(void);
  * LCF_OPT_CONV_SPLIT: how many waves share one 16-row tile of the indice_conv forward by
  * splitting its output columns: 1, 2 or 4; 0 (default) = choose from the row count. */
 #define LCF_OPT_CONV_SPLIT 0
+/* LCF_OPT_CONV_IMPL: 0 (default) = tile-compacted forward, 1 = first-generation slab forward
+ * (kept for A/B timing; host row counts and <= 8192 padded weights per offset only). */
+#define LCF_OPT_CONV_IMPL 1
 int lcf_set_option(int option, int value);
 
 /* ------------------------------------------------------------------------------------------
@@ -57,11 +64,14 @@ int lcf_set_option(int option, int value);
  * first-come loop: voxel ids in order of first appearance, the first max_pts points (by index)
  * kept per voxel.  cap_mode 0 = `break` when a new voxel would exceed max_vox (numba twin),
  * 1 = `continue` (spconv C++ behaviour).  vs / range are HOST arrays.
+ * coor_stride 3 writes (z,y,x); coor_stride 4 writes (batch_idx,z,y,x), i.e. the batch column
+ * that merge_second_batch (second/data/preprocess.py:44-50) pads on the host.
  */
 size_t lcf_voxelize_workspace_bytes(int n, int max_pts);
-int lcf_voxelize(const float *points, int n, int f, const float vs[3], const float range[6],
-                 int max_pts, int max_vox, int cap_mode, float *voxels, int *coors,
-                 int *num_pts, int *voxel_num, void *ws, size_t ws_bytes, void *stream);
+int lcf_voxelize(const float *points, int n, const int *n_dev, int f, const float vs[3],
+                 const float range[6], int max_pts, int max_vox, int cap_mode, int batch_idx,
+                 int coor_stride, float *voxels, int *coors, int *num_pts, int *voxel_num,
+                 void *ws, size_t ws_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Rulebooks (spconv.ops.get_indice_pairs as called by SparseConvolution.forward for
@@ -78,28 +88,33 @@ int lcf_voxelize(const float *points, int n, int f, const float vs[3], const flo
  * coors [k,4] i32 (b,z,y,x).  shape/ksize/stride/pad/dil are HOST int[3] (z,y,x order).
  */
 size_t lcf_rulebook_subm_workspace_bytes(int k);
-int lcf_rulebook_subm(const int *coors, int k, int batch, const int shape[3],
+int lcf_rulebook_subm(const int *coors, int k, const int *k_dev, int batch, const int shape[3],
                       const int ksize[3], const int dil[3], int *out_nbr, void *ws,
                       size_t ws_bytes, void *stream);
 
-/* Strided / ordinary sparse conv, two phases (the caller reads *k_out between them to size
- * the tables, exactly as spconv synchronises to size its output):
- *   discover: out_coors [cap_out,4] in CPU-discovery (canonical) order, *k_out (device i32);
- *             cap_out >= lcf_rulebook_conv_max_out(k_in, ksize, stride).
- *   fill:     out_nbr [k_out,kvol], in_nbr [k_in,kvol]; needs the SAME ws untouched in between.
+/* Strided / ordinary sparse conv, two phases.  Either the caller reads *k_out between them to
+ * size the tables exactly (as spconv synchronises to size its output), or it passes capacities
+ * and the device count to `fill` and never synchronises.
+ *   discover: out_coors [cap_out,4] in CPU-discovery (canonical) order, *k_out (device i32,
+ *             clamped to cap_out).  cap_out may be below the worst case
+ *             lcf_rulebook_conv_max_out(k_in, ksize, stride) only when `overflow` (device i32,
+ *             zeroed by the caller) is given: it is set to 1 if outputs were dropped.
+ *   fill:     out_nbr [k_out,kvol], in_nbr [k_in,kvol] (NULL = not wanted: inference needs
+ *             out_nbr only); needs the SAME ws untouched in between.
  */
 int lcf_rulebook_conv_max_out(int k_in, const int ksize[3], const int stride[3]);
 void lcf_conv_out_shape(const int shape[3], const int ksize[3], const int stride[3],
                         const int pad[3], const int dil[3], int out_shape[3]);
 size_t lcf_rulebook_conv_workspace_bytes(int k_in, const int ksize[3], const int stride[3]);
-int lcf_rulebook_conv_discover(const int *coors, int k_in, int batch, const int shape[3],
-                               const int ksize[3], const int stride[3], const int pad[3],
-                               const int dil[3], int *out_coors, int cap_out, int *k_out,
-                               void *ws, size_t ws_bytes, void *stream);
-int lcf_rulebook_conv_fill(const int *coors, int k_in, int batch, const int shape[3],
-                           const int ksize[3], const int stride[3], const int pad[3],
-                           const int dil[3], int k_out, int *out_nbr, int *in_nbr, void *ws,
-                           size_t ws_bytes, void *stream);
+int lcf_rulebook_conv_discover(const int *coors, int k_in, const int *k_in_dev, int batch,
+                               const int shape[3], const int ksize[3], const int stride[3],
+                               const int pad[3], const int dil[3], int *out_coors, int cap_out,
+                               int *k_out, int *overflow, void *ws, size_t ws_bytes,
+                               void *stream);
+int lcf_rulebook_conv_fill(const int *coors, int k_in, const int *k_in_dev, int batch,
+                           const int shape[3], const int ksize[3], const int stride[3],
+                           const int pad[3], const int dil[3], int k_out, const int *k_out_dev,
+                           int *out_nbr, int *in_nbr, void *ws, size_t ws_bytes, void *stream);
 
 /* mirror a submanifold table: in_nbr[j][o] = out_nbr[j][kvol-1-o] */
 int lcf_rulebook_mirror(const int *nbr, int k, int kvol, int *mirrored, void *stream);
@@ -119,7 +134,9 @@ int lcf_rulebook_pairs(const int *in_nbr, int k_in, int kvol, int *pairs, int *p
  * fwd : out[n,:] = act( (sum_o feat[out_nbr[n][o],:] @ W[o]) * scale + shift ), offsets
  *       ascending, fp32 FMA accumulation on the fp32 MFMA pipe.  scale/shift [cout] may be
  *       NULL (identity; shift alone = bias); relu != 0 applies max(x,0).  This one kernel is
- *       the fused gather-GEMM-scatter: the scatter is the row's own store.
+ *       the fused gather-GEMM-scatter: the scatter is the row's own store.  nbr == NULL with
+ *       kvol == 1 is the identity table: a row-wise linear layer (spconv's kernel_size == 1
+ *       short cut to torch.mm, second/pytorch/models/resnet.py:20-29; the VFE Linear layers).
  * dgrad = the same entry point with in_nbr and the transposed image.
  * wgrad: dw[o] (+)= feat[j,:]^T dout[in_nbr[j][o],:]  -> dw [kvol,cin,cout] f32 (zeroed inside).
  */
@@ -127,8 +144,8 @@ size_t lcf_weight_image_elems(int kvol, int cin, int cout, int transpose);
 int lcf_weight_image(const float *w, int kvol, int cin, int cout, int transpose, float *img,
                      void *stream);
 int lcf_indice_conv_fwd(const float *feat, const float *wimg, const int *nbr, int k_out,
-                        int kvol, int cin, int cout, const float *scale, const float *shift,
-                        int relu, float *out, void *stream);
+                        const int *k_out_dev, int kvol, int cin, int cout, const float *scale,
+                        const float *shift, int relu, float *out, void *stream);
 int lcf_indice_conv_wgrad(const float *feat, const float *dout, const int *in_nbr, int k_in,
                           int kvol, int cin, int cout, float *dw, void *stream);
 
@@ -136,8 +153,8 @@ int lcf_indice_conv_wgrad(const float *feat, const float *dout, const int *in_nb
  * SparseConvTensor.dense() (second/pytorch/models/middle.py:206): out [B,C,D,H,W] f32 is
  * zero-filled and scattered from feat [k,c], coors [k,4].  dense_bwd gathers it back.
  */
-int lcf_dense(const float *feat, const int *coors, int k, int c, int batch, const int shape[3],
-              float *out, void *stream);
+int lcf_dense(const float *feat, const int *coors, int k, const int *k_dev, int c, int batch,
+              const int shape[3], float *out, void *stream);
 int lcf_dense_bwd(const float *dout, const int *coors, int k, int c, int batch,
                   const int shape[3], float *dfeat, void *stream);
 
@@ -153,12 +170,12 @@ int lcf_dense_bwd(const float *dout, const int *coors, int k, int c, int batch,
  *              mode 1: out [k,u]    = max_t (y * mask[k,t])               (final max-pool)
  *            with mask[k,t] = t < num[k]  (get_paddings_indicator :27-48).
  */
-int lcf_vfe_mean(const float *voxels, const int *num, int k, int t, int f, int c, float *out,
-                 void *stream);
-int lcf_vfe_augment(const float *voxels, const int *num, int k, int t, int f, float *out,
-                    void *stream);
-int lcf_vfe_pool(const float *x, const int *num, int k, int t, int u, const float *scale,
-                 const float *shift, int mode, float *out, void *stream);
+int lcf_vfe_mean(const float *voxels, const int *num, int k, const int *k_dev, int t, int f,
+                 int c, float *out, void *stream);
+int lcf_vfe_augment(const float *voxels, const int *num, int k, const int *k_dev, int t, int f,
+                    float *out, void *stream);
+int lcf_vfe_pool(const float *x, const int *num, int k, const int *k_dev, int t, int u,
+                 const float *scale, const float *shift, int mode, float *out, void *stream);
 
 #ifdef __cplusplus
 }

@@ -22,37 +22,41 @@ SYMBOLS = {
     "lcf_version": (c_int, []),
     "lcf_set_option": (c_int, [c_int, c_int]),
     "lcf_voxelize_workspace_bytes": (c_size_t, [c_int, c_int]),
-    "lcf_voxelize": (c_int, [c_void_p, c_int, c_int, _PF, _PF, c_int, c_int, c_int, c_void_p,
-                             c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "lcf_voxelize": (c_int, [c_void_p, c_int, c_void_p, c_int, _PF, _PF, c_int, c_int, c_int,
+                             c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                             c_size_t, c_void_p]),
     "lcf_rulebook_subm_workspace_bytes": (c_size_t, [c_int]),
-    "lcf_rulebook_subm": (c_int, [c_void_p, c_int, c_int, _PI3, _PI3, _PI3, c_void_p, c_void_p,
-                                  c_size_t, c_void_p]),
+    "lcf_rulebook_subm": (c_int, [c_void_p, c_int, c_void_p, c_int, _PI3, _PI3, _PI3, c_void_p,
+                                  c_void_p, c_size_t, c_void_p]),
     "lcf_rulebook_conv_max_out": (c_int, [c_int, _PI3, _PI3]),
     "lcf_conv_out_shape": (None, [_PI3, _PI3, _PI3, _PI3, _PI3, _PI3]),
     "lcf_rulebook_conv_workspace_bytes": (c_size_t, [c_int, _PI3, _PI3]),
-    "lcf_rulebook_conv_discover": (c_int, [c_void_p, c_int, c_int, _PI3, _PI3, _PI3, _PI3, _PI3,
-                                           c_void_p, c_int, c_void_p, c_void_p, c_size_t,
-                                           c_void_p]),
-    "lcf_rulebook_conv_fill": (c_int, [c_void_p, c_int, c_int, _PI3, _PI3, _PI3, _PI3, _PI3,
-                                       c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "lcf_rulebook_conv_discover": (c_int, [c_void_p, c_int, c_void_p, c_int, _PI3, _PI3, _PI3,
+                                           _PI3, _PI3, c_void_p, c_int, c_void_p, c_void_p,
+                                           c_void_p, c_size_t, c_void_p]),
+    "lcf_rulebook_conv_fill": (c_int, [c_void_p, c_int, c_void_p, c_int, _PI3, _PI3, _PI3, _PI3,
+                                       _PI3, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                       c_size_t, c_void_p]),
     "lcf_rulebook_mirror": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "lcf_rulebook_pairs_workspace_bytes": (c_size_t, [c_int, c_int]),
     "lcf_rulebook_pairs": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                    c_size_t, c_void_p]),
     "lcf_weight_image_elems": (c_size_t, [c_int, c_int, c_int, c_int]),
     "lcf_weight_image": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
-    "lcf_indice_conv_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
-                                    c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "lcf_indice_conv_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int,
+                                    c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "lcf_indice_conv_wgrad": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                       c_void_p, c_void_p]),
-    "lcf_dense": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, _PI3, c_void_p, c_void_p]),
+    "lcf_dense": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, _PI3, c_void_p,
+                          c_void_p]),
     "lcf_dense_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, _PI3, c_void_p,
                               c_void_p]),
-    "lcf_vfe_mean": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
+    "lcf_vfe_mean": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p,
                              c_void_p]),
-    "lcf_vfe_augment": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
-    "lcf_vfe_pool": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int,
-                             c_void_p, c_void_p]),
+    "lcf_vfe_augment": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p,
+                                c_void_p]),
+    "lcf_vfe_pool": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p,
+                             c_void_p, c_int, c_void_p, c_void_p]),
 }
 
 _lib = None

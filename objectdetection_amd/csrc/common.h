@@ -13,6 +13,12 @@
         if (hipGetLastError() != hipSuccess) return LCF_ERR_LAUNCH; \
     } while (0)
 
+// Device fill used instead of hipMemsetAsync for every internal reset: a plain kernel node
+// behaves the same eagerly and under hipGraph capture / replay.  `bytes` must be a multiple of 4
+// and `p` 4-byte aligned (every workspace region is 256-byte aligned).
+__global__ void lcf_fill32_kernel(uint32_t *p, uint32_t v, size_t n32);
+int lcf_fill32(void *p, uint32_t v, size_t bytes, hipStream_t st);
+
 static inline size_t lcf_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 static inline uint32_t lcf_pow2_ge(uint32_t x)
@@ -20,6 +26,17 @@ static inline uint32_t lcf_pow2_ge(uint32_t x)
     uint32_t p = 1;
     while (p < x) p <<= 1;
     return p;
+}
+
+// Row counts come as (capacity, optional device pointer): with a device pointer the kernels read
+// the actual count from memory (clamped to the capacity) and the launch geometry depends on the
+// capacity only, so no host synchronisation is needed to size a launch.
+__device__ __forceinline__ int lcf_count(int cap, const int *dev)
+{
+    if (!dev) return cap;
+    int v = *dev;
+    v = v < 0 ? 0 : v;
+    return v < cap ? v : cap;
 }
 
 // 32-bit integer hash (murmur3 finaliser)

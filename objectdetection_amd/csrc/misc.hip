@@ -16,14 +16,45 @@ extern "C" const char *lcf_strerror(int rc)
 
 extern "C" int lcf_version(void) { return 100; }
 
+__global__ void __launch_bounds__(256) lcf_fill32_kernel(uint32_t *p, uint32_t v, size_t n32)
+{
+    // 16-byte stores over the aligned body, scalar head/tail
+    size_t head = ((16 - ((uintptr_t)p & 15)) & 15) / 4;
+    if (head > n32) head = n32;
+    size_t body = (n32 - head) / 4;
+    uint4 *p4 = reinterpret_cast<uint4 *>(p + head);
+    const uint4 v4 = make_uint4(v, v, v, v);
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (size_t i = t; i < body; i += stride) p4[i] = v4;
+    if (t < head) p[t] = v;
+    size_t tail0 = head + body * 4;
+    if (t < n32 - tail0) p[tail0 + t] = v;
+}
+
+int lcf_fill32(void *p, uint32_t v, size_t bytes, hipStream_t st)
+{
+    if (bytes == 0) return LCF_OK;
+    if ((bytes & 3) || ((uintptr_t)p & 3)) return LCF_ERR_ARG;
+    size_t n32 = bytes / 4;
+    size_t nb = (n32 / 4 + 255) / 256;
+    if (nb < 1) nb = 1;
+    if (nb > 4096) nb = 4096;
+    lcf_fill32_kernel<<<(unsigned)nb, 256, 0, st>>>((uint32_t *)p, v, n32);
+    LCF_CHECK_LAUNCH();
+    return LCF_OK;
+}
+
 // ---------------------------------------------------------------- dense
 // SparseConvTensor.dense() (second/pytorch/models/middle.py:206): [B,C,D,H,W] contiguous.
 // Thread = (row, channel); a row's C values land C*svol*4 bytes apart, so writes are scattered by
-// construction -- the bulk traffic is the zero fill, done by hipMemsetAsync at copy-engine rate.
+// construction -- the bulk traffic is the zero fill, done by a 16-byte-store fill kernel.
 __global__ void __launch_bounds__(256)
-dense_scatter_kernel(const float *__restrict__ feat, const int *__restrict__ coors, int k, int c,
-                     int batch, int D, int H, int W, float *__restrict__ out)
+dense_scatter_kernel(const float *__restrict__ feat, const int *__restrict__ coors, int k_cap,
+                     const int *__restrict__ k_dev, int c, int batch, int D, int H, int W,
+                     float *__restrict__ out)
 {
+    const int k = lcf_count(k_cap, k_dev);
     long long t = (long long)blockIdx.x * 256 + threadIdx.x;
     if (t >= (long long)k * c) return;
     int row = (int)(t / c), ch = (int)(t - (long long)row * c);
@@ -54,18 +85,18 @@ dense_gather_kernel(const float *__restrict__ dout, const int *__restrict__ coor
     dfeat[t] = v;
 }
 
-extern "C" int lcf_dense(const float *feat, const int *coors, int k, int c, int batch,
-                         const int shape[3], float *out, void *stream)
+extern "C" int lcf_dense(const float *feat, const int *coors, int k, const int *k_dev, int c,
+                         int batch, const int shape[3], float *out, void *stream)
 {
     if (k < 0 || c <= 0 || batch <= 0 || !shape || !out || (k > 0 && (!feat || !coors)))
         return LCF_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     size_t bytes = (size_t)batch * c * shape[0] * shape[1] * shape[2] * 4;
-    if (hipMemsetAsync(out, 0, bytes, st) != hipSuccess) return LCF_ERR_LAUNCH;
+    if (lcf_fill32(out, 0u, bytes, st) != LCF_OK) return LCF_ERR_LAUNCH;
     if (k == 0) return LCF_OK;
     long long total = (long long)k * c;
     dense_scatter_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(
-        feat, coors, k, c, batch, shape[0], shape[1], shape[2], out);
+        feat, coors, k, k_dev, c, batch, shape[0], shape[1], shape[2], out);
     LCF_CHECK_LAUNCH();
     return LCF_OK;
 }
@@ -87,9 +118,10 @@ extern "C" int lcf_dense_bwd(const float *dout, const int *coors, int k, int c, 
 // SimpleVoxel.forward (voxel_encoder.py:220-225): sum over T (padding rows are zero) / num.
 // The sum runs t = 0..T-1 in order, as torch's reduction over a 5-long dim does.
 __global__ void __launch_bounds__(256)
-vfe_mean_kernel(const float *__restrict__ voxels, const int *__restrict__ num, int k, int t,
-                int f, int c, float *__restrict__ out)
+vfe_mean_kernel(const float *__restrict__ voxels, const int *__restrict__ num, int k_cap,
+                const int *__restrict__ k_dev, int t, int f, int c, float *__restrict__ out)
 {
+    const int k = lcf_count(k_cap, k_dev);
     long long id = (long long)blockIdx.x * 256 + threadIdx.x;
     if (id >= (long long)k * c) return;
     int v = (int)(id / c), ch = (int)(id - (long long)v * c);
@@ -101,9 +133,10 @@ vfe_mean_kernel(const float *__restrict__ voxels, const int *__restrict__ num, i
 
 // VoxelFeatureExtractor.forward :116-124: out[k,t,:] = [voxels[k,t,:f], voxels[k,t,:3]-mean]
 __global__ void __launch_bounds__(256)
-vfe_augment_kernel(const float *__restrict__ voxels, const int *__restrict__ num, int k, int t,
-                   int f, float *__restrict__ out)
+vfe_augment_kernel(const float *__restrict__ voxels, const int *__restrict__ num, int k_cap,
+                   const int *__restrict__ k_dev, int t, int f, float *__restrict__ out)
 {
+    const int k = lcf_count(k_cap, k_dev);
     long long id = (long long)blockIdx.x * 256 + threadIdx.x;
     if (id >= (long long)k * t) return;
     int v = (int)(id / t);
@@ -124,10 +157,11 @@ vfe_augment_kernel(const float *__restrict__ voxels, const int *__restrict__ num
 // Thread = (voxel, channel); walks the T points of its voxel (stride u floats: the 64 lanes of a
 // wave read 64 consecutive channels = 256 contiguous bytes per point row).
 __global__ void __launch_bounds__(256)
-vfe_pool_kernel(const float *__restrict__ x, const int *__restrict__ num, int k, int t, int u,
-                const float *__restrict__ scale, const float *__restrict__ shift, int mode,
-                float *__restrict__ out)
+vfe_pool_kernel(const float *__restrict__ x, const int *__restrict__ num, int k_cap,
+                const int *__restrict__ k_dev, int t, int u, const float *__restrict__ scale,
+                const float *__restrict__ shift, int mode, float *__restrict__ out)
 {
+    const int k = lcf_count(k_cap, k_dev);
     long long id = (long long)blockIdx.x * 256 + threadIdx.x;
     if (id >= (long long)k * u) return;
     int v = (int)(id / u), ch = (int)(id - (long long)v * u);
@@ -159,33 +193,33 @@ vfe_pool_kernel(const float *__restrict__ x, const int *__restrict__ num, int k,
     }
 }
 
-extern "C" int lcf_vfe_mean(const float *voxels, const int *num, int k, int t, int f, int c,
-                            float *out, void *stream)
+extern "C" int lcf_vfe_mean(const float *voxels, const int *num, int k, const int *k_dev, int t,
+                            int f, int c, float *out, void *stream)
 {
     if (k < 0 || t <= 0 || f <= 0 || c <= 0 || c > f || (k > 0 && (!voxels || !num || !out)))
         return LCF_ERR_ARG;
     if (k == 0) return LCF_OK;
     long long total = (long long)k * c;
     vfe_mean_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(
-        voxels, num, k, t, f, c, out);
+        voxels, num, k, k_dev, t, f, c, out);
     LCF_CHECK_LAUNCH();
     return LCF_OK;
 }
 
-extern "C" int lcf_vfe_augment(const float *voxels, const int *num, int k, int t, int f,
-                               float *out, void *stream)
+extern "C" int lcf_vfe_augment(const float *voxels, const int *num, int k, const int *k_dev,
+                               int t, int f, float *out, void *stream)
 {
     if (k < 0 || t <= 0 || f < 3 || (k > 0 && (!voxels || !num || !out))) return LCF_ERR_ARG;
     if (k == 0) return LCF_OK;
     long long total = (long long)k * t;
     vfe_augment_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(
-        voxels, num, k, t, f, out);
+        voxels, num, k, k_dev, t, f, out);
     LCF_CHECK_LAUNCH();
     return LCF_OK;
 }
 
-extern "C" int lcf_vfe_pool(const float *x, const int *num, int k, int t, int u,
-                            const float *scale, const float *shift, int mode, float *out,
+extern "C" int lcf_vfe_pool(const float *x, const int *num, int k, const int *k_dev, int t,
+                            int u, const float *scale, const float *shift, int mode, float *out,
                             void *stream)
 {
     if (k < 0 || t <= 0 || u <= 0 || mode < 0 || mode > 1 || (k > 0 && (!x || !num || !out)))
@@ -193,7 +227,7 @@ extern "C" int lcf_vfe_pool(const float *x, const int *num, int k, int t, int u,
     if (k == 0) return LCF_OK;
     long long total = (long long)k * u;
     vfe_pool_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(
-        x, num, k, t, u, scale, shift, mode, out);
+        x, num, k, k_dev, t, u, scale, shift, mode, out);
     LCF_CHECK_LAUNCH();
     return LCF_OK;
 }

@@ -37,9 +37,11 @@ __device__ __forceinline__ uint32_t rb_key(int b, int z, int y, int x, const int
 // ---------------------------------------------------------------- submanifold
 
 __global__ void __launch_bounds__(RB_BLOCK)
-rb_subm_insert_kernel(const int *__restrict__ coors, int k, int batch, ConvGeom g,
-                      uint32_t *__restrict__ keys, uint32_t mask, int *__restrict__ vals)
+rb_subm_insert_kernel(const int *__restrict__ coors, int k_cap, const int *__restrict__ k_dev,
+                      int batch, ConvGeom g, uint32_t *__restrict__ keys, uint32_t mask,
+                      int *__restrict__ vals)
 {
+    const int k = lcf_count(k_cap, k_dev);
     int j = blockIdx.x * RB_BLOCK + threadIdx.x;
     if (j >= k) return;
     int4 c = reinterpret_cast<const int4 *>(coors)[j];
@@ -51,10 +53,11 @@ rb_subm_insert_kernel(const int *__restrict__ coors, int k, int batch, ConvGeom 
 }
 
 __global__ void __launch_bounds__(RB_BLOCK)
-rb_subm_lookup_kernel(const int *__restrict__ coors, int k, int batch, ConvGeom g,
-                      const uint32_t *__restrict__ keys, uint32_t mask,
+rb_subm_lookup_kernel(const int *__restrict__ coors, int k_cap, const int *__restrict__ k_dev,
+                      int batch, ConvGeom g, const uint32_t *__restrict__ keys, uint32_t mask,
                       const int *__restrict__ vals, int *__restrict__ nbr)
 {
+    const int k = lcf_count(k_cap, k_dev);
     long long t = (long long)blockIdx.x * RB_BLOCK + threadIdx.x;
     if (t >= (long long)k * g.kvol) return;
     int n = (int)(t / g.kvol);
@@ -125,10 +128,11 @@ __device__ __forceinline__ bool rb_candidate(const int4 c, int e, const ConvGeom
 }
 
 __global__ void __launch_bounds__(RB_BLOCK)
-rb_conv_insert_kernel(const int *__restrict__ coors, int k_in, int batch, ConvGeom g,
-                      unsigned long long *__restrict__ tab, uint32_t mask,
+rb_conv_insert_kernel(const int *__restrict__ coors, int k_cap, const int *__restrict__ k_dev,
+                      int batch, ConvGeom g, unsigned long long *__restrict__ tab, uint32_t mask,
                       int *__restrict__ cand_slot)
 {
+    const int k_in = lcf_count(k_cap, k_dev);
     long long t = (long long)blockIdx.x * RB_BLOCK + threadIdx.x;
     if (t >= (long long)k_in * g.E) return;
     int j = (int)(t / g.E);
@@ -167,10 +171,11 @@ __device__ __forceinline__ int rb_is_discoverer(const unsigned long long *tab,
 
 __global__ void __launch_bounds__(RB_BLOCK)
 rb_conv_count_kernel(const unsigned long long *__restrict__ tab,
-                     const int *__restrict__ cand_slot, long long total,
-                     int *__restrict__ bsums)
+                     const int *__restrict__ cand_slot, int k_cap,
+                     const int *__restrict__ k_dev, int E, int *__restrict__ bsums)
 {
     __shared__ int lds[8];
+    const long long total = (long long)lcf_count(k_cap, k_dev) * E;
     long long base = ((long long)blockIdx.x * RB_BLOCK + threadIdx.x) * RB_ITEMS;
     int cnt = 0;
 #pragma unroll
@@ -182,12 +187,13 @@ rb_conv_count_kernel(const unsigned long long *__restrict__ tab,
 
 __global__ void __launch_bounds__(RB_BLOCK)
 rb_conv_assign_kernel(const unsigned long long *__restrict__ tab,
-                      const int *__restrict__ cand_slot, long long total,
-                      const int *__restrict__ bsums, ConvGeom g, int cap_out,
-                      int *__restrict__ vals, int *__restrict__ out_coors,
-                      int *__restrict__ k_out)
+                      const int *__restrict__ cand_slot, int k_cap,
+                      const int *__restrict__ k_dev, const int *__restrict__ bsums, ConvGeom g,
+                      int cap_out, int *__restrict__ vals, int *__restrict__ out_coors,
+                      int *__restrict__ k_out, int *__restrict__ overflow)
 {
     __shared__ int lds[8];
+    const long long total = (long long)lcf_count(k_cap, k_dev) * g.E;
     int part = 0;
     for (int b = threadIdx.x; b < (int)blockIdx.x; b += RB_BLOCK) part += bsums[b];
     int blockbase;
@@ -220,14 +226,21 @@ rb_conv_assign_kernel(const unsigned long long *__restrict__ tab,
             ++ex;
         }
     }
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) k_out[0] = blockbase + tot;
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+        const int n = blockbase + tot;
+        k_out[0] = n < cap_out ? n : cap_out; // outputs past the capacity are dropped ...
+        if (n > cap_out && overflow) overflow[0] = 1; // ... and reported
+    }
 }
 
 __global__ void __launch_bounds__(RB_BLOCK)
-rb_conv_fill_kernel(const int *__restrict__ coors, int k_in, int batch, ConvGeom g, int k_out,
+rb_conv_fill_kernel(const int *__restrict__ coors, int k_cap, const int *__restrict__ k_dev,
+                    int batch, ConvGeom g, int k_out_cap, const int *__restrict__ k_out_dev,
                     const int *__restrict__ cand_slot, const int *__restrict__ vals,
                     int *__restrict__ out_nbr, int *__restrict__ in_nbr)
 {
+    const int k_in = lcf_count(k_cap, k_dev);
+    const int k_out = lcf_count(k_out_cap, k_out_dev);
     long long t = (long long)blockIdx.x * RB_BLOCK + threadIdx.x;
     if (t >= (long long)k_in * g.E) return;
     int h = cand_slot[t];
@@ -240,7 +253,7 @@ rb_conv_fill_kernel(const int *__restrict__ coors, int k_in, int batch, ConvGeom
     int n = vals[h];
     if (n >= k_out) return;
     out_nbr[(size_t)n * g.kvol + off] = j;
-    in_nbr[(size_t)j * g.kvol + off] = n;
+    if (in_nbr) in_nbr[(size_t)j * g.kvol + off] = n;
 }
 
 // ---------------------------------------------------------------- canonical pair lists
@@ -361,9 +374,9 @@ extern "C" size_t lcf_rulebook_subm_workspace_bytes(int k)
     return lcf_align_up((size_t)hc * 4, 256) * 2;
 }
 
-extern "C" int lcf_rulebook_subm(const int *coors, int k, int batch, const int shape[3],
-                                 const int ksize[3], const int dil[3], int *out_nbr, void *ws,
-                                 size_t ws_bytes, void *stream)
+extern "C" int lcf_rulebook_subm(const int *coors, int k, const int *k_dev, int batch,
+                                 const int shape[3], const int ksize[3], const int dil[3],
+                                 int *out_nbr, void *ws, size_t ws_bytes, void *stream)
 {
     if (k < 0 || (k > 0 && (!coors || !out_nbr)) || !ws) return LCF_ERR_ARG;
     ConvGeom g;
@@ -376,13 +389,13 @@ extern "C" int lcf_rulebook_subm(const int *coors, int k, int batch, const int s
     uint32_t *keys = (uint32_t *)ws;
     int *vals = (int *)((char *)ws + lcf_align_up((size_t)hc * 4, 256));
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(keys, 0xFF, (size_t)hc * 4, st) != hipSuccess) return LCF_ERR_LAUNCH;
-    rb_subm_insert_kernel<<<(k + RB_BLOCK - 1) / RB_BLOCK, RB_BLOCK, 0, st>>>(coors, k, batch, g,
-                                                                             keys, hc - 1, vals);
+    if (lcf_fill32(keys, 0xFFFFFFFFu, (size_t)hc * 4, st) != LCF_OK) return LCF_ERR_LAUNCH;
+    rb_subm_insert_kernel<<<(k + RB_BLOCK - 1) / RB_BLOCK, RB_BLOCK, 0, st>>>(
+        coors, k, k_dev, batch, g, keys, hc - 1, vals);
     LCF_CHECK_LAUNCH();
     long long total = (long long)k * g.kvol;
     rb_subm_lookup_kernel<<<(unsigned)((total + RB_BLOCK - 1) / RB_BLOCK), RB_BLOCK, 0, st>>>(
-        coors, k, batch, g, keys, hc - 1, vals, out_nbr);
+        coors, k, k_dev, batch, g, keys, hc - 1, vals, out_nbr);
     LCF_CHECK_LAUNCH();
     return LCF_OK;
 }
@@ -448,11 +461,12 @@ extern "C" size_t lcf_rulebook_conv_workspace_bytes(int k_in, const int ksize[3]
     return rb_conv_carve(nullptr, k_in, (int)e).bytes;
 }
 
-extern "C" int lcf_rulebook_conv_discover(const int *coors, int k_in, int batch,
-                                          const int shape[3], const int ksize[3],
+extern "C" int lcf_rulebook_conv_discover(const int *coors, int k_in, const int *k_in_dev,
+                                          int batch, const int shape[3], const int ksize[3],
                                           const int stride[3], const int pad[3],
                                           const int dil[3], int *out_coors, int cap_out,
-                                          int *k_out, void *ws, size_t ws_bytes, void *stream)
+                                          int *k_out, int *overflow, void *ws, size_t ws_bytes,
+                                          void *stream)
 {
     if (k_in < 0 || !stride || !pad || !k_out || !ws || (k_in > 0 && (!coors || !out_coors)))
         return LCF_ERR_ARG;
@@ -462,32 +476,36 @@ extern "C" int lcf_rulebook_conv_discover(const int *coors, int k_in, int batch,
     ConvWs w = rb_conv_carve(ws, k_in, g.E);
     if (w.total >= 0x7FFFFFFFll) return LCF_ERR_RANGE;
     if (ws_bytes < w.bytes) return LCF_ERR_WORKSPACE;
-    if (cap_out < lcf_rulebook_conv_max_out(k_in, ksize, stride)) return LCF_ERR_ARG;
+    if (cap_out < 0 || (!overflow && cap_out < lcf_rulebook_conv_max_out(k_in, ksize, stride)))
+        return LCF_ERR_ARG; // a capacity below the worst case needs somewhere to report overflow
     hipStream_t st = (hipStream_t)stream;
     if (k_in == 0) {
-        if (hipMemsetAsync(k_out, 0, 4, st) != hipSuccess) return LCF_ERR_LAUNCH;
+        if (lcf_fill32(k_out, 0u, 4, st) != LCF_OK) return LCF_ERR_LAUNCH;
         return LCF_OK;
     }
-    if (hipMemsetAsync(w.tab, 0xFF, (size_t)w.hc * 8, st) != hipSuccess) return LCF_ERR_LAUNCH;
+    if (lcf_fill32(w.tab, 0xFFFFFFFFu, (size_t)w.hc * 8, st) != LCF_OK) return LCF_ERR_LAUNCH;
     unsigned nb = (unsigned)((w.total + RB_BLOCK - 1) / RB_BLOCK);
-    rb_conv_insert_kernel<<<nb, RB_BLOCK, 0, st>>>(coors, k_in, batch, g, w.tab, w.hc - 1,
-                                                   w.cand_slot);
+    rb_conv_insert_kernel<<<nb, RB_BLOCK, 0, st>>>(coors, k_in, k_in_dev, batch, g, w.tab,
+                                                   w.hc - 1, w.cand_slot);
     LCF_CHECK_LAUNCH();
-    rb_conv_count_kernel<<<w.nblk, RB_BLOCK, 0, st>>>(w.tab, w.cand_slot, w.total, w.bsums);
+    rb_conv_count_kernel<<<w.nblk, RB_BLOCK, 0, st>>>(w.tab, w.cand_slot, k_in, k_in_dev, g.E,
+                                                      w.bsums);
     LCF_CHECK_LAUNCH();
-    rb_conv_assign_kernel<<<w.nblk, RB_BLOCK, 0, st>>>(w.tab, w.cand_slot, w.total, w.bsums, g,
-                                                       cap_out, w.vals, out_coors, k_out);
+    rb_conv_assign_kernel<<<w.nblk, RB_BLOCK, 0, st>>>(w.tab, w.cand_slot, k_in, k_in_dev, w.bsums,
+                                                       g, cap_out, w.vals, out_coors, k_out,
+                                                       overflow);
     LCF_CHECK_LAUNCH();
     return LCF_OK;
 }
 
-extern "C" int lcf_rulebook_conv_fill(const int *coors, int k_in, int batch, const int shape[3],
-                                      const int ksize[3], const int stride[3], const int pad[3],
-                                      const int dil[3], int k_out, int *out_nbr, int *in_nbr,
-                                      void *ws, size_t ws_bytes, void *stream)
+extern "C" int lcf_rulebook_conv_fill(const int *coors, int k_in, const int *k_in_dev, int batch,
+                                      const int shape[3], const int ksize[3],
+                                      const int stride[3], const int pad[3], const int dil[3],
+                                      int k_out, const int *k_out_dev, int *out_nbr,
+                                      int *in_nbr, void *ws, size_t ws_bytes, void *stream)
 {
-    if (k_in < 0 || k_out < 0 || !stride || !pad || !ws ||
-        (k_in > 0 && (!coors || !in_nbr)) || (k_out > 0 && !out_nbr))
+    if (k_in < 0 || k_out < 0 || !stride || !pad || !ws || (k_in > 0 && !coors) ||
+        (k_out > 0 && !out_nbr))
         return LCF_ERR_ARG;
     ConvGeom g;
     int rc = rb_geom(&g, batch, shape, ksize, stride, pad, dil, false);
@@ -496,14 +514,15 @@ extern "C" int lcf_rulebook_conv_fill(const int *coors, int k_in, int batch, con
     if (ws_bytes < w.bytes) return LCF_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     if (k_out > 0 &&
-        hipMemsetAsync(out_nbr, 0xFF, (size_t)k_out * g.kvol * 4, st) != hipSuccess)
+        lcf_fill32(out_nbr, 0xFFFFFFFFu, (size_t)k_out * g.kvol * 4, st) != LCF_OK)
         return LCF_ERR_LAUNCH;
-    if (k_in > 0 && hipMemsetAsync(in_nbr, 0xFF, (size_t)k_in * g.kvol * 4, st) != hipSuccess)
+    if (k_in > 0 && in_nbr &&
+        lcf_fill32(in_nbr, 0xFFFFFFFFu, (size_t)k_in * g.kvol * 4, st) != LCF_OK)
         return LCF_ERR_LAUNCH;
     if (k_in == 0 || k_out == 0) return LCF_OK;
     unsigned nb = (unsigned)((w.total + RB_BLOCK - 1) / RB_BLOCK);
-    rb_conv_fill_kernel<<<nb, RB_BLOCK, 0, st>>>(coors, k_in, batch, g, k_out, w.cand_slot,
-                                                 w.vals, out_nbr, in_nbr);
+    rb_conv_fill_kernel<<<nb, RB_BLOCK, 0, st>>>(coors, k_in, k_in_dev, batch, g, k_out, k_out_dev,
+                                                 w.cand_slot, w.vals, out_nbr, in_nbr);
     LCF_CHECK_LAUNCH();
     return LCF_OK;
 }
@@ -525,12 +544,12 @@ extern "C" int lcf_rulebook_pairs(const int *in_nbr, int k_in, int kvol, int *pa
     if (ws_bytes < lcf_rulebook_pairs_workspace_bytes(k_in, kvol)) return LCF_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     if (k_in == 0) {
-        if (hipMemsetAsync(pair_num, 0, (size_t)kvol * 4, st) != hipSuccess) return LCF_ERR_LAUNCH;
+        if (lcf_fill32(pair_num, 0u, (size_t)kvol * 4, st) != LCF_OK) return LCF_ERR_LAUNCH;
         return LCF_OK;
     }
     int nblk = (k_in + RB_BLOCK - 1) / RB_BLOCK;
     int *bcnt = (int *)ws;
-    if (hipMemsetAsync(pairs, 0xFF, (size_t)2 * kvol * k_in * 4, st) != hipSuccess)
+    if (lcf_fill32(pairs, 0xFFFFFFFFu, (size_t)2 * kvol * k_in * 4, st) != LCF_OK)
         return LCF_ERR_LAUNCH;
     rb_pairs_count_kernel<<<nblk, RB_BLOCK, 0, st>>>(in_nbr, k_in, kvol, bcnt);
     LCF_CHECK_LAUNCH();

@@ -27,10 +27,11 @@ struct VoxParams {
 };
 
 __global__ void __launch_bounds__(VOX_BLOCK)
-vox_insert_kernel(const float *__restrict__ pts, int n, int f, VoxParams p, int max_pts,
-                  uint32_t *__restrict__ keys, uint32_t mask, int *__restrict__ lists,
-                  int *__restrict__ cellslot)
+vox_insert_kernel(const float *__restrict__ pts, int n_cap, const int *__restrict__ n_dev, int f,
+                  VoxParams p, int max_pts, uint32_t *__restrict__ keys, uint32_t mask,
+                  int *__restrict__ lists, int *__restrict__ cellslot)
 {
+    const int n = lcf_count(n_cap, n_dev);
     int i = blockIdx.x * VOX_BLOCK + threadIdx.x;
     if (i >= n) return;
     int c[3];
@@ -72,9 +73,11 @@ __device__ __forceinline__ int vox_is_first(const int *cellslot, const int *list
 
 __global__ void __launch_bounds__(VOX_BLOCK)
 vox_count_kernel(const int *__restrict__ cellslot, const int *__restrict__ lists, int max_pts,
-                 int n, int *__restrict__ bsums, int *__restrict__ ctrl)
+                 int n_cap, const int *__restrict__ n_dev, int *__restrict__ bsums,
+                 int *__restrict__ ctrl)
 {
     __shared__ int lds[8];
+    const int n = lcf_count(n_cap, n_dev);
     int base = (blockIdx.x * VOX_BLOCK + threadIdx.x) * VOX_ITEMS;
     int cnt = 0;
 #pragma unroll
@@ -89,10 +92,12 @@ vox_count_kernel(const int *__restrict__ cellslot, const int *__restrict__ lists
 
 __global__ void __launch_bounds__(VOX_BLOCK)
 vox_assign_kernel(const int *__restrict__ cellslot, const int *__restrict__ lists, int max_pts,
-                  int n, const int *__restrict__ bsums, int max_vox, int *__restrict__ pvid,
-                  int *__restrict__ ctrl, int *__restrict__ voxel_num)
+                  int n_cap, const int *__restrict__ n_dev, const int *__restrict__ bsums,
+                  int max_vox, int *__restrict__ pvid, int *__restrict__ ctrl,
+                  int *__restrict__ voxel_num)
 {
     __shared__ int lds[8];
+    const int n = lcf_count(n_cap, n_dev);
     // prefix of the preceding blocks' sums
     int part = 0;
     for (int b = threadIdx.x; b < (int)blockIdx.x; b += VOX_BLOCK) part += bsums[b];
@@ -123,21 +128,21 @@ vox_assign_kernel(const int *__restrict__ cellslot, const int *__restrict__ list
 }
 
 __global__ void __launch_bounds__(VOX_BLOCK)
-vox_emit_kernel(const float *__restrict__ pts, int n, int f, VoxParams p, int max_pts,
-                int max_vox, int cap_mode, const uint32_t *__restrict__ keys,
+vox_emit_kernel(const float *__restrict__ pts, int n_cap, const int *__restrict__ n_dev, int f,
+                VoxParams p, int max_pts, int max_vox, int cap_mode, int batch_idx, int cstride,
+                const uint32_t *__restrict__ keys,
                 const int *__restrict__ lists, const int *__restrict__ cellslot,
                 const int *__restrict__ pvid, const int *__restrict__ ctrl,
                 const int *__restrict__ voxel_num, float *__restrict__ voxels,
                 int *__restrict__ coors, int *__restrict__ num_pts)
 {
+    const int n = lcf_count(n_cap, n_dev);
     int i = blockIdx.x * VOX_BLOCK + threadIdx.x;
     // (a) zero the rows beyond voxel_num (padded outputs of generate_multi_gpu)
     if (i < max_vox && i >= voxel_num[0]) {
         float *row = voxels + (size_t)i * max_pts * f;
         for (int e = 0; e < max_pts * f; ++e) row[e] = 0.f;
-        coors[i * 3 + 0] = 0;
-        coors[i * 3 + 1] = 0;
-        coors[i * 3 + 2] = 0;
+        for (int e = 0; e < cstride; ++e) coors[i * cstride + e] = 0;
         num_pts[i] = 0;
     }
     if (i >= n) return;
@@ -171,9 +176,11 @@ vox_emit_kernel(const float *__restrict__ pts, int n, int f, VoxParams p, int ma
         for (int e = cnt * f; e < max_pts * f; ++e) row[e] = 0.f;
         uint32_t key = keys[h];
         uint32_t gx = (uint32_t)p.grid[0], gy = (uint32_t)p.grid[1];
-        coors[vid * 3 + 2] = (int)(key % gx);
-        coors[vid * 3 + 1] = (int)((key / gx) % gy);
-        coors[vid * 3 + 0] = (int)(key / (gx * gy));
+        int *cr = coors + (size_t)vid * cstride + (cstride - 3);
+        cr[2] = (int)(key % gx);
+        cr[1] = (int)((key / gx) % gy);
+        cr[0] = (int)(key / (gx * gy));
+        if (cstride == 4) coors[(size_t)vid * 4] = batch_idx; // merge_second_batch's batch column
     }
 }
 
@@ -216,13 +223,15 @@ extern "C" size_t lcf_voxelize_workspace_bytes(int n, int max_pts)
     return vox_carve(nullptr, n, max_pts).bytes;
 }
 
-extern "C" int lcf_voxelize(const float *points, int n, int f, const float vs[3],
-                            const float range[6], int max_pts, int max_vox, int cap_mode,
-                            float *voxels, int *coors, int *num_pts, int *voxel_num, void *ws,
-                            size_t ws_bytes, void *stream)
+extern "C" int lcf_voxelize(const float *points, int n, const int *n_dev, int f,
+                            const float vs[3], const float range[6], int max_pts, int max_vox,
+                            int cap_mode, int batch_idx, int coor_stride, float *voxels,
+                            int *coors, int *num_pts, int *voxel_num, void *ws, size_t ws_bytes,
+                            void *stream)
 {
     if (n < 0 || f < 3 || max_pts <= 0 || max_vox <= 0 || !vs || !range || !voxels || !coors ||
-        !num_pts || !voxel_num || !ws || (n > 0 && !points) || cap_mode < 0 || cap_mode > 1)
+        !num_pts || !voxel_num || !ws || (n > 0 && !points) || cap_mode < 0 || cap_mode > 1 ||
+        (coor_stride != 3 && coor_stride != 4))
         return LCF_ERR_ARG;
     if (n >= VOX_SENT - VOX_BLOCK * VOX_ITEMS) return LCF_ERR_RANGE;
     VoxParams p;
@@ -240,24 +249,24 @@ extern "C" int lcf_voxelize(const float *points, int n, int f, const float vs[3]
     VoxWs w = vox_carve(ws, n, max_pts);
     if (ws_bytes < w.bytes) return LCF_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(w.keys, 0xFF, (size_t)w.hc * 4, st) != hipSuccess) return LCF_ERR_LAUNCH;
-    if (hipMemsetAsync(w.lists, 0x7F, (size_t)w.hc * max_pts * 4, st) != hipSuccess)
+    if (lcf_fill32(w.keys, 0xFFFFFFFFu, (size_t)w.hc * 4, st) != LCF_OK) return LCF_ERR_LAUNCH;
+    if (lcf_fill32(w.lists, (uint32_t)VOX_SENT, (size_t)w.hc * max_pts * 4, st) != LCF_OK)
         return LCF_ERR_LAUNCH;
     if (n > 0) {
         vox_insert_kernel<<<(n + VOX_BLOCK - 1) / VOX_BLOCK, VOX_BLOCK, 0, st>>>(
-            points, n, f, p, max_pts, w.keys, w.hc - 1, w.lists, w.cellslot);
+            points, n, n_dev, f, p, max_pts, w.keys, w.hc - 1, w.lists, w.cellslot);
         LCF_CHECK_LAUNCH();
     }
-    vox_count_kernel<<<w.nblk, VOX_BLOCK, 0, st>>>(w.cellslot, w.lists, max_pts, n, w.bsums,
-                                                   w.ctrl);
+    vox_count_kernel<<<w.nblk, VOX_BLOCK, 0, st>>>(w.cellslot, w.lists, max_pts, n, n_dev,
+                                                   w.bsums, w.ctrl);
     LCF_CHECK_LAUNCH();
-    vox_assign_kernel<<<w.nblk, VOX_BLOCK, 0, st>>>(w.cellslot, w.lists, max_pts, n, w.bsums,
-                                                    max_vox, w.pvid, w.ctrl, voxel_num);
+    vox_assign_kernel<<<w.nblk, VOX_BLOCK, 0, st>>>(w.cellslot, w.lists, max_pts, n, n_dev,
+                                                    w.bsums, max_vox, w.pvid, w.ctrl, voxel_num);
     LCF_CHECK_LAUNCH();
     int m = n > max_vox ? n : max_vox;
     vox_emit_kernel<<<(m + VOX_BLOCK - 1) / VOX_BLOCK, VOX_BLOCK, 0, st>>>(
-        points, n, f, p, max_pts, max_vox, cap_mode, w.keys, w.lists, w.cellslot, w.pvid, w.ctrl,
-        voxel_num, voxels, coors, num_pts);
+        points, n, n_dev, f, p, max_pts, max_vox, cap_mode, batch_idx, coor_stride, w.keys, w.lists,
+        w.cellslot, w.pvid, w.ctrl, voxel_num, voxels, coors, num_pts);
     LCF_CHECK_LAUNCH();
     return LCF_OK;
 }

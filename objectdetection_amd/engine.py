@@ -1,0 +1,336 @@
+"""FrameEngine: the whole hot path of one frame as ONE hipGraph replay, no host synchronisation.
+
+The reference runs voxelisation on the host (second/data/preprocess.py:626-639), copies the
+arrays to the GPU (second/pytorch/train.py:27-55) and then steps through ~40 Python modules
+(VoxelNet.network_forward, second/pytorch/models/voxelnet.py:314-333); spconv synchronises once
+per strided conv to size its outputs.  At batch 1 the path moves a few MB, so it is bound by
+launch latency and those synchronisations, not by the kernels.
+
+MI355X form: every row count of the path (points, voxels, active sites of each level) stays in
+device memory.  liblcf's entry points take (capacity, device count) pairs (include/lcf.h), the
+buffers are allocated once for the capacities -- 288 GB of HBM makes generous capacities free --
+and the ~60 launches of a frame are captured into a hipGraph that is replayed per frame.
+The sparse middle is bit-identical to the module-by-module path (same kernels, same order); the
+three VFE Linear layers run on liblcf's fp32-MFMA row-wise linear kernel instead of a library
+GEMM, so M2 features agree to fp32 rounding (~1e-6 relative) rather than bit for bit.
+
+Every internal buffer reset is a fill KERNEL (lcf_fill32), not hipMemsetAsync: on ROCm 7.2 a
+captured graph holding hipMemsetAsync nodes hung at its second replay on this path.
+
+Capacities of the strided levels are calibrated on sample frames (x ``margin``); a frame that
+exceeds them sets a device flag, reported by ``check()`` (``forward(..., sync=True)`` re-plans
+with larger capacities and re-runs the frame on its own).
+"""
+import torch
+from torch import nn
+
+from . import _lib, ops
+from ._lib import check, f3, f6, i3
+from .spconv.conv import SparseConvolution
+from .spconv.modules import _bn_affine
+from .voxel_encoder import SimpleVoxel, VoxelFeatureExtractor, _affine
+
+
+def _round_up(x, m):
+    return (int(x) + m - 1) // m * m
+
+
+class _Layer:
+    pass
+
+
+class FrameEngine:
+    def __init__(self, model, max_points=None, calib=None, margin=1.5, use_graph=True):
+        """model: objectdetection_amd.frontend.SparseFrontEnd in eval mode on a GPU.
+        max_points: capacity of the point buffer (default: 2 x the largest calibration cloud).
+        calib: list of [N,F] float32 cuda clouds used to size the strided levels."""
+        p = next(model.parameters(), None)
+        self.dev = p.device if p is not None else torch.device("cuda", torch.cuda.current_device())
+        if self.dev.type != "cuda":
+            raise RuntimeError("FrameEngine runs on the GPU only")
+        if model.training:
+            raise RuntimeError("FrameEngine folds BatchNorm: put the model in eval() mode")
+        self.model = model
+        self.L = _lib.lib()
+        self.use_graph = use_graph
+        self.margin = float(margin)
+        vg = model.voxel_generator
+        self.vs = [float(x) for x in vg.voxel_size]
+        self.rng = [float(x) for x in vg.point_cloud_range]
+        self.T = int(vg.max_num_points_per_voxel)
+        self.max_voxels = int(model.max_voxels)
+        self.cap_mode = int(vg._cap_mode)
+        self.F = 4
+        vfe = model.voxel_feature_extractor
+        if isinstance(vfe, VoxelFeatureExtractor) and not vfe._with_distance:
+            self.vfe_kind = "vfe"
+        elif type(vfe) is SimpleVoxel:
+            self.vfe_kind = "mean"
+        else:
+            raise NotImplementedError(f"FrameEngine: unsupported VFE {type(vfe).__name__}")
+        mid = model.middle_feature_extractor
+        self.sparse_shape = [int(x) for x in mid.sparse_shape]
+        self._parse_middle(list(mid.middle_conv))
+        calib = list(calib or [])
+        if max_points is None:
+            max_points = 2 * max([c.shape[0] for c in calib] + [16384])
+        self.max_points = int(max_points)
+        self.graph = None
+        self.level_caps = None
+        # plan with worst-case-ish capacities, measure, then re-plan tight and capture
+        self._plan(None)
+        if calib:
+            need = None
+            for c in calib:
+                self._load(c)
+                self._enqueue()
+                ks = self.counts()
+                if self.overflowed():
+                    raise RuntimeError("FrameEngine: calibration frame exceeds the loose caps")
+                need = ks if need is None else [max(a, b) for a, b in zip(need, ks)]
+            self._plan([_round_up(self.margin * k + 2048, 1024) for k in need[1:]])
+        if use_graph:
+            self._capture()
+
+    # ------------------------------------------------------------------ static description
+    def _parse_middle(self, mods):
+        self.layers = []
+        i = 0
+        shape = list(self.sparse_shape)
+        while i < len(mods):
+            conv = mods[i]
+            if not isinstance(conv, SparseConvolution) or conv.ndim != 3:
+                raise NotImplementedError("FrameEngine: middle_conv must be 3-D sparse convs")
+            bn, relu = None, False
+            j = i + 1
+            if j < len(mods) and isinstance(mods[j], nn.BatchNorm1d):
+                bn = mods[j]
+                j += 1
+            elif j < len(mods) and not isinstance(mods[j], (nn.ReLU, SparseConvolution)):
+                j += 1  # identity placeholder (use_norm=False)
+            if j < len(mods) and isinstance(mods[j], nn.ReLU):
+                relu = True
+                j += 1
+            l = _Layer()
+            l.conv, l.bn, l.relu = conv, bn, relu
+            l.subm = conv.subm
+            l.key = conv.indice_key
+            l.cin, l.cout = conv.in_channels, conv.out_channels
+            l.ksize = list(conv.kernel_size)
+            l.kvol = l.ksize[0] * l.ksize[1] * l.ksize[2]
+            l.stride, l.pad, l.dil = list(conv.stride), list(conv.padding), list(conv.dilation)
+            l.in_shape = list(shape)
+            if not l.subm:
+                shape = ops.conv_out_shape(shape, l.ksize, l.stride, l.pad, l.dil)
+            l.out_shape = list(shape)
+            self.layers.append(l)
+            i = j
+        self.out_shape = shape
+        self.n_strided = sum(1 for l in self.layers if not l.subm)
+
+    def _fold(self):
+        """Weight images and folded BatchNorm (eval) of every layer; VFE linear images."""
+        with torch.no_grad():
+            for l in self.layers:
+                l.wimg = ops.weight_image(l.conv.weight)
+                scale = shift = None
+                if l.bn is not None:
+                    scale, shift = _bn_affine(l.bn)
+                if l.conv.bias is not None:
+                    b = l.conv.bias.float()
+                    shift = (b * scale + shift) if scale is not None else b
+                l.scale = None if scale is None else scale.contiguous()
+                l.shift = None if shift is None else shift.contiguous()
+            if self.vfe_kind == "vfe":
+                vfe = self.model.voxel_feature_extractor
+                self.lin = []
+                for lin, norm in ((vfe.vfe1.linear, vfe.vfe1.norm), (vfe.vfe2.linear, vfe.vfe2.norm),
+                                  (vfe.linear, vfe.norm)):
+                    w = lin.weight.detach().float().t().contiguous()  # [in, out]
+                    cin, cout = w.shape
+                    scale, shift = _affine(norm, cout, w.device)
+                    if lin.bias is not None:
+                        b = lin.bias.detach().float()
+                        shift = (b * scale + shift) if scale is not None else b
+                    self.lin.append((ops.weight_image(w.view(1, cin, cout)), cin, cout,
+                                     scale, None if shift is None else shift.contiguous()))
+
+    # ------------------------------------------------------------------ buffers
+    def _plan(self, caps):
+        """Allocate every buffer of a frame.  caps: capacity of each strided level's output (rows);
+        None = loose (worst-case bounded) capacities used for calibration."""
+        dev, L = self.dev, self.L
+        i32, f32 = torch.int32, torch.float32
+        MV, T, F = self.max_voxels, self.T, self.F
+        E = lambda *s, dtype=f32: torch.empty(s, dtype=dtype, device=dev)
+        self._fold()
+        self.points = E(self.max_points, F)
+        self.n_dev = torch.zeros(1, dtype=i32, device=dev)
+        self.voxels, self.coors = E(MV, T, F), E(MV, 4, dtype=i32)
+        self.num, self.vnum = E(MV, dtype=i32), torch.zeros(1, dtype=i32, device=dev)
+        self.vox_ws = E(max(L.lcf_voxelize_workspace_bytes(self.max_points, T), 256),
+                        dtype=torch.uint8)
+        self.flags = torch.zeros(max(self.n_strided, 1), dtype=i32, device=dev)
+        if self.vfe_kind == "vfe":
+            (_, c0, u1, _, _), (_, _, u2, _, _), (_, _, u3, _, _) = self.lin
+            self.kt = torch.zeros(1, dtype=i32, device=dev)
+            self.aug = E(MV, T, c0)
+            self.x1, self.p1 = E(MV * T, u1), E(MV, T, 2 * u1)
+            self.x2, self.p2 = E(MV * T, u2), E(MV, T, 2 * u2)
+            self.x3 = E(MV * T, u3)
+            self.feat0 = E(MV, u3)
+        else:
+            self.feat0 = E(MV, self.layers[0].cin)
+        # middle: level = (coors, count scalar, capacity); rulebooks per key / per strided conv
+        cap = MV
+        si = 0
+        self.level_caps = [MV]
+        keys = {}
+        for l in self.layers:
+            l.k_in_cap = cap
+            if l.subm:
+                if l.key is not None and l.key in keys and keys[l.key].k_in_cap == cap:
+                    l.rb_owner = keys[l.key]
+                else:
+                    l.rb_owner = l
+                    l.nbr = E(cap, l.kvol, dtype=i32)
+                    l.ws = E(max(L.lcf_rulebook_subm_workspace_bytes(cap), 256), dtype=torch.uint8)
+                    if l.key is not None:
+                        keys[l.key] = l
+                l.k_out_cap = cap
+            else:
+                worst = L.lcf_rulebook_conv_max_out(cap, i3(l.ksize), i3(l.stride))
+                cells = l.out_shape[0] * l.out_shape[1] * l.out_shape[2]
+                loose = min(worst, cells, 8 * MV)
+                l.k_out_cap = loose if caps is None else min(int(caps[si]), min(worst, cells))
+                l.k_out_cap = max(l.k_out_cap, 64)
+                l.flag = self.flags[si:si + 1]
+                si += 1
+                l.out_coors = E(l.k_out_cap, 4, dtype=i32)
+                l.k_out = torch.zeros(1, dtype=i32, device=dev)
+                l.nbr = E(l.k_out_cap, l.kvol, dtype=i32)
+                l.ws = E(max(L.lcf_rulebook_conv_workspace_bytes(cap, i3(l.ksize), i3(l.stride)),
+                             256), dtype=torch.uint8)
+                l.rb_owner = l
+                cap = l.k_out_cap
+                self.level_caps.append(cap)
+            l.out = E(l.k_out_cap, l.cout)
+        C = self.layers[-1].cout
+        D, H, W = self.out_shape
+        self.dense = E(1, C, D, H, W)
+        self.out = self.dense.view(1, C * D, H, W)
+        self.graph = None
+
+    # ------------------------------------------------------------------ one frame, enqueued
+    def _enqueue(self):
+        L = self.L
+        st = torch.cuda.current_stream().cuda_stream
+        P = lambda t: None if t is None else t.data_ptr()
+        MV, T, F = self.max_voxels, self.T, self.F
+        self.flags.zero_()
+        check(L.lcf_voxelize(P(self.points), self.max_points, P(self.n_dev), F, f3(self.vs),
+                             f6(self.rng), T, MV, self.cap_mode, 0, 4, P(self.voxels),
+                             P(self.coors), P(self.num), P(self.vnum), P(self.vox_ws),
+                             self.vox_ws.numel(), st))
+        kd = self.vnum
+        if self.vfe_kind == "vfe":
+            torch.mul(self.vnum, T, out=self.kt)
+            (w1, c0, u1, s1, h1), (w2, _, u2, s2, h2), (w3, _, u3, s3, h3) = self.lin
+            check(L.lcf_vfe_augment(P(self.voxels), P(self.num), MV, P(kd), T, F, P(self.aug), st))
+            for x_in, cin, (w, cout, sc, sh), x_out, pool_out, mode in (
+                    (self.aug, c0, (w1, u1, s1, h1), self.x1, self.p1, 0),
+                    (self.p1, 2 * u1, (w2, u2, s2, h2), self.x2, self.p2, 0),
+                    (self.p2, 2 * u2, (w3, u3, s3, h3), self.x3, self.feat0, 1)):
+                check(L.lcf_indice_conv_fwd(P(x_in), P(w), None, MV * T, P(self.kt), 1, cin, cout,
+                                            P(sc), P(sh), 1, P(x_out), st))
+                check(L.lcf_vfe_pool(P(x_out), P(self.num), MV, P(kd), T, cout, None, None, mode,
+                                     P(pool_out), st))
+        else:
+            check(L.lcf_vfe_mean(P(self.voxels), P(self.num), MV, P(kd), T, F,
+                                 self.layers[0].cin, P(self.feat0), st))
+        feat, coors = self.feat0, self.coors
+        built = set()
+        for l in self.layers:
+            o = l.rb_owner
+            if l.subm:
+                if id(o) not in built:
+                    check(L.lcf_rulebook_subm(P(coors), o.k_in_cap, P(kd), 1, i3(l.in_shape),
+                                              i3(l.ksize), i3(l.dil), P(o.nbr), P(o.ws),
+                                              o.ws.numel(), st))
+                    built.add(id(o))
+                k_out_cap, k_out_dev = l.k_in_cap, kd
+            else:
+                geo = (1, i3(l.in_shape), i3(l.ksize), i3(l.stride), i3(l.pad), i3(l.dil))
+                check(L.lcf_rulebook_conv_discover(P(coors), l.k_in_cap, P(kd), *geo,
+                                                   P(l.out_coors), l.k_out_cap, P(l.k_out),
+                                                   P(l.flag), P(l.ws), l.ws.numel(), st))
+                check(L.lcf_rulebook_conv_fill(P(coors), l.k_in_cap, P(kd), *geo, l.k_out_cap,
+                                               P(l.k_out), P(l.nbr), None, P(l.ws), l.ws.numel(),
+                                               st))
+                k_out_cap, k_out_dev = l.k_out_cap, l.k_out
+            check(L.lcf_indice_conv_fwd(P(feat), P(l.wimg), P(o.nbr), k_out_cap, P(k_out_dev),
+                                        l.kvol, l.cin, l.cout, P(l.scale), P(l.shift),
+                                        int(l.relu), P(l.out), st))
+            feat = l.out
+            if not l.subm:
+                coors, kd = l.out_coors, l.k_out
+        check(L.lcf_dense(P(feat), P(coors), feat.shape[0], P(kd), feat.shape[1], 1,
+                          i3(self.out_shape), P(self.dense), st))
+
+    def _capture(self):
+        s = torch.cuda.Stream(device=self.dev)
+        s.wait_stream(torch.cuda.current_stream(self.dev))
+        with torch.cuda.stream(s):  # warm-up outside capture (function attributes, lazy init)
+            self._enqueue()
+        torch.cuda.current_stream(self.dev).wait_stream(s)
+        torch.cuda.synchronize(self.dev)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._enqueue()
+        self.graph = g
+
+    # ------------------------------------------------------------------ public
+    def _load(self, points):
+        n = int(points.shape[0])
+        if n > self.max_points:
+            raise RuntimeError(f"FrameEngine: {n} points exceed max_points={self.max_points}")
+        if points.shape[1] != self.F or points.dtype != torch.float32 or not points.is_cuda:
+            raise ValueError("points must be a [N,4] float32 cuda tensor")
+        self.points[:n].copy_(points, non_blocking=True)
+        self.n_dev.fill_(n)
+
+    def forward(self, points, sync=False):
+        """points [N,4] f32 cuda -> [1, C*D, H, W] (the engine's static output buffer: consume or
+        clone it before the next call).  Nothing here waits for the GPU unless sync=True."""
+        self._load(points)
+        if self.graph is not None:
+            self.graph.replay()
+        else:
+            self._enqueue()
+        if sync:
+            if self.overflowed():
+                ks = self.counts()
+                self.margin *= 2
+                self._plan(None)  # loose capacities; a later calibrate() tightens them again
+                if self.use_graph:
+                    self._capture()
+                return self.forward(points, sync=True)
+        return self.out
+
+    __call__ = forward
+
+    def overflowed(self):
+        """True if the last frame exceeded a level capacity (synchronises)."""
+        return bool(self.flags.any().item())
+
+    def check(self):
+        if self.overflowed():
+            raise RuntimeError(
+                "FrameEngine: a strided level exceeded its capacity "
+                f"{self.level_caps}; re-create the engine with a larger margin or calibrate on "
+                "denser frames (or call forward(..., sync=True), which re-plans by itself)")
+
+    def counts(self):
+        """[voxels, active sites after each strided conv] of the last frame (synchronises)."""
+        ks = [self.vnum] + [l.k_out for l in self.layers if not l.subm]
+        return [int(x) for x in torch.cat(ks).tolist()]

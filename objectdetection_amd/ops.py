@@ -50,10 +50,15 @@ def to3(v):
 
 # ------------------------------------------------------------------ voxelizer
 
-def voxelize(points, voxel_size, pc_range, max_points, max_voxels, cap_mode=0):
+def voxelize(points, voxel_size, pc_range, max_points, max_voxels, cap_mode=0, n_dev=None,
+             batch_idx=None, out=None, ws=None):
     """points [N,F] f32 cuda -> (voxels [max_voxels,T,F], coors [max_voxels,3] zyx,
     num_points [max_voxels], voxel_num [1] i32 device).  Rows >= voxel_num are zero.
-    Bit-identical to the reference's sequential loop (include/lcf.h: lcf_voxelize)."""
+    Bit-identical to the reference's sequential loop (include/lcf.h: lcf_voxelize).
+
+    ``n_dev`` ([1] int32 cuda): the number of valid points lives on the device (N is then the
+    capacity).  ``batch_idx`` not None: coors come out as [max_voxels,4] (batch_idx,z,y,x).
+    ``out`` = (voxels, coors, num, voxel_num) and ``ws`` reuse caller-owned buffers."""
     _need_cuda(points)
     if points.dtype != torch.float32 or points.dim() != 2:
         raise ValueError("points must be a [N,F] float32 tensor")
@@ -61,15 +66,20 @@ def voxelize(points, voxel_size, pc_range, max_points, max_voxels, cap_mode=0):
     n, f = pts.shape
     dev = pts.device
     L = _lib.lib()
-    voxels = torch.empty((max_voxels, max_points, f), dtype=torch.float32, device=dev)
-    coors = torch.empty((max_voxels, 3), dtype=torch.int32, device=dev)
-    num = torch.empty((max_voxels,), dtype=torch.int32, device=dev)
-    vnum = torch.empty((1,), dtype=torch.int32, device=dev)
-    wsb = L.lcf_voxelize_workspace_bytes(n, max_points)
-    ws = _ws(wsb, dev)
-    check(L.lcf_voxelize(_ptr(pts), n, f, f3(voxel_size), f6(pc_range), int(max_points),
-                         int(max_voxels), int(cap_mode), _ptr(voxels), _ptr(coors), _ptr(num),
-                         _ptr(vnum), _ptr(ws), ws.numel(), _stream()))
+    cs = 3 if batch_idx is None else 4
+    if out is None:
+        voxels = torch.empty((max_voxels, max_points, f), dtype=torch.float32, device=dev)
+        coors = torch.empty((max_voxels, cs), dtype=torch.int32, device=dev)
+        num = torch.empty((max_voxels,), dtype=torch.int32, device=dev)
+        vnum = torch.empty((1,), dtype=torch.int32, device=dev)
+    else:
+        voxels, coors, num, vnum = out
+    if ws is None:
+        ws = _ws(L.lcf_voxelize_workspace_bytes(n, max_points), dev)
+    check(L.lcf_voxelize(_ptr(pts), n, _ptr(n_dev), f, f3(voxel_size), f6(pc_range),
+                         int(max_points), int(max_voxels), int(cap_mode), int(batch_idx or 0), cs,
+                         _ptr(voxels), _ptr(coors), _ptr(num), _ptr(vnum), _ptr(ws), ws.numel(),
+                         _stream()))
     return voxels, coors, num, vnum
 
 
@@ -170,7 +180,7 @@ def build_rulebook(indices, batch_size, spatial_shape, ksize, stride, padding, d
     if subm:
         nbr = torch.empty((k, kvol), dtype=torch.int32, device=dev)
         ws = _ws(L.lcf_rulebook_subm_workspace_bytes(k), dev)
-        check(L.lcf_rulebook_subm(_ptr(ind), k, int(batch_size), i3(shape), i3(ksize),
+        check(L.lcf_rulebook_subm(_ptr(ind), k, None, int(batch_size), i3(shape), i3(ksize),
                                   i3(dilation), _ptr(nbr), _ptr(ws), ws.numel(), _stream()))
         return Rulebook(True, ind, ind, shape, shape, ksize, [1, 1, 1],
                         [(a // 2) * d for a, d in zip(ksize, dilation)], dilation, nbr, None)
@@ -181,14 +191,14 @@ def build_rulebook(indices, batch_size, spatial_shape, ksize, stride, padding, d
     ws = _ws(L.lcf_rulebook_conv_workspace_bytes(k, i3(ksize), i3(stride)), dev)
     out_c = torch.empty((max(cap, 1), 4), dtype=torch.int32, device=dev)
     kout_t = torch.empty((1,), dtype=torch.int32, device=dev)
-    args = (_ptr(ind), k, int(batch_size), i3(shape), i3(ksize), i3(stride), i3(padding),
+    args = (_ptr(ind), k, None, int(batch_size), i3(shape), i3(ksize), i3(stride), i3(padding),
             i3(dilation))
-    check(L.lcf_rulebook_conv_discover(*args, _ptr(out_c), int(max(cap, 1)), _ptr(kout_t),
+    check(L.lcf_rulebook_conv_discover(*args, _ptr(out_c), int(max(cap, 1)), _ptr(kout_t), None,
                                        _ptr(ws), ws.numel(), _stream()))
     k_out = int(kout_t.item())  # the one host sync per strided conv, as in spconv
     out_nbr = torch.empty((k_out, kvol), dtype=torch.int32, device=dev)
     in_nbr = torch.empty((k, kvol), dtype=torch.int32, device=dev)
-    check(L.lcf_rulebook_conv_fill(*args, k_out, _ptr(out_nbr), _ptr(in_nbr), _ptr(ws),
+    check(L.lcf_rulebook_conv_fill(*args, k_out, None, _ptr(out_nbr), _ptr(in_nbr), _ptr(ws),
                                    ws.numel(), _stream()))
     return Rulebook(False, ind, out_c[:k_out].clone(), shape, oshape, ksize, stride, padding,
                     dilation, out_nbr, in_nbr)
@@ -215,14 +225,20 @@ def weight_image(weight, transpose=False):
 
 
 def conv_forward(features, wimg, nbr, n_rows, kvol, cin, cout, scale=None, shift=None,
-                 relu=False):
-    """out[n_rows,cout] = act((sum_o features[nbr[n][o]] @ W[o]) * scale + shift)."""
+                 relu=False, n_rows_dev=None, out=None):
+    """out[n_rows,cout] = act((sum_o features[nbr[n][o]] @ W[o]) * scale + shift).
+
+    ``nbr=None`` with ``kvol=1`` is the identity table (a plain row-wise linear layer).
+    ``n_rows_dev`` ([1] int32 cuda): the actual row count lives on the device, ``n_rows`` is
+    then the capacity (rows past the device count are left untouched)."""
     _need_cuda(features, wimg, nbr)
     x = features.contiguous()
-    out = torch.empty((n_rows, cout), dtype=torch.float32, device=x.device)
-    check(_lib.lib().lcf_indice_conv_fwd(_ptr(x), _ptr(wimg), _ptr(nbr), int(n_rows), int(kvol),
-                                         int(cin), int(cout), _ptr(scale), _ptr(shift),
-                                         int(bool(relu)), _ptr(out), _stream()))
+    if out is None:
+        out = torch.empty((n_rows, cout), dtype=torch.float32, device=x.device)
+    check(_lib.lib().lcf_indice_conv_fwd(_ptr(x), _ptr(wimg), _ptr(nbr), int(n_rows),
+                                         _ptr(n_rows_dev), int(kvol), int(cin), int(cout),
+                                         _ptr(scale), _ptr(shift), int(bool(relu)), _ptr(out),
+                                         _stream()))
     return out
 
 
@@ -277,8 +293,8 @@ class DenseFunction(torch.autograd.Function):
         x = features.float().contiguous()
         k, c = x.shape
         out = torch.empty((batch_size, c, *shape), dtype=torch.float32, device=x.device)
-        check(_lib.lib().lcf_dense(_ptr(x), _ptr(indices), k, c, int(batch_size), i3(shape),
-                                   _ptr(out), _stream()))
+        check(_lib.lib().lcf_dense(_ptr(x), _ptr(indices), k, None, c, int(batch_size),
+                                   i3(shape), _ptr(out), _stream()))
         ctx.save_for_backward(indices)
         ctx.meta = (k, c, int(batch_size), list(shape), features.dtype)
         return out.to(features.dtype)
@@ -307,8 +323,8 @@ def vfe_mean(voxels, num_points, c):
     v = voxels.contiguous()
     k, t, f = v.shape
     out = torch.empty((k, c), dtype=torch.float32, device=v.device)
-    check(_lib.lib().lcf_vfe_mean(_ptr(v), _ptr(num_points.int().contiguous()), k, t, f, int(c),
-                                  _ptr(out), _stream()))
+    check(_lib.lib().lcf_vfe_mean(_ptr(v), _ptr(num_points.int().contiguous()), k, None, t, f,
+                                  int(c), _ptr(out), _stream()))
     return out
 
 
@@ -317,8 +333,8 @@ def vfe_augment(voxels, num_points):
     v = voxels.contiguous()
     k, t, f = v.shape
     out = torch.empty((k, t, f + 3), dtype=torch.float32, device=v.device)
-    check(_lib.lib().lcf_vfe_augment(_ptr(v), _ptr(num_points.int().contiguous()), k, t, f,
-                                     _ptr(out), _stream()))
+    check(_lib.lib().lcf_vfe_augment(_ptr(v), _ptr(num_points.int().contiguous()), k, None, t,
+                                     f, _ptr(out), _stream()))
     return out
 
 
@@ -328,6 +344,6 @@ def vfe_pool(x, num_points, scale, shift, mode):
     k, t, u = x.shape
     shape = (k, t, 2 * u) if mode == 0 else (k, u)
     out = torch.empty(shape, dtype=torch.float32, device=x.device)
-    check(_lib.lib().lcf_vfe_pool(_ptr(x), _ptr(num_points.int().contiguous()), k, t, u,
+    check(_lib.lib().lcf_vfe_pool(_ptr(x), _ptr(num_points.int().contiguous()), k, None, t, u,
                                   _ptr(scale), _ptr(shift), int(mode), _ptr(out), _stream()))
     return out

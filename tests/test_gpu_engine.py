@@ -1,0 +1,63 @@
+"""GPU: the graph-captured FrameEngine (no host sync, device-side row counts) reproduces the
+module-by-module path bit for bit, across frames of different sizes, and reports overflow."""
+import pytest
+import torch
+
+from objectdetection_amd import synth
+from objectdetection_amd.frontend import SparseFrontEnd, randomize_
+
+pytestmark = pytest.mark.gpu
+
+
+def _clouds(cuda, seeds, n):
+    return [torch.from_numpy(synth.vkitti_frame(s, n)).to(cuda) for s in seeds]
+
+
+@pytest.mark.parametrize("name", ["M1", "M2"])
+def test_engine_matches_eager(cuda, name):
+    model = randomize_(SparseFrontEnd(name).eval(), 0).to(cuda)
+    calib = _clouds(cuda, [0, 1], 20000)
+    with torch.no_grad():
+        eng = model.engine(calib=calib)
+        # frames of different sizes through the SAME captured graph, in arbitrary order
+        for seed, n in [(0, 20000), (5, 12000), (1, 20000), (7, 3000), (5, 12000)]:
+            c = torch.from_numpy(synth.vkitti_frame(seed, n)).to(cuda)
+            out = eng.forward(c).clone()
+            eng.check()
+            ref = model([c])
+            assert out.shape == ref.shape
+            if name == "M1":  # same kernels in the same order: bit-identical
+                assert torch.equal(out, ref)
+            else:  # M2: VFE Linear layers on the fp32-MFMA linear kernel vs a library GEMM
+                err = (out - ref).abs().max() / ref.abs().max()
+                assert err.item() < 1e-4  # the north-star fp32 feature tolerance
+                assert torch.equal(out != 0, ref != 0) or err.item() < 1e-5
+        ks = eng.counts()
+        assert ks[0] > 0 and len(ks) == 1 + eng.n_strided
+
+
+def test_engine_without_graph_and_empty_frame(cuda):
+    model = randomize_(SparseFrontEnd("M1").eval(), 0).to(cuda)
+    with torch.no_grad():
+        eng = model.engine(calib=_clouds(cuda, [0], 8000), use_graph=False)
+        c = _clouds(cuda, [3], 8000)[0]
+        assert torch.equal(eng.forward(c), model([c]))
+        empty = torch.zeros((0, 4), device=cuda)
+        out = eng.forward(empty)
+        assert eng.counts()[0] == 0
+        assert float(out.abs().max()) == 0.0
+
+
+def test_engine_overflow_is_reported_and_replanned(cuda):
+    model = randomize_(SparseFrontEnd("M1").eval(), 0).to(cuda)
+    small = _clouds(cuda, [0], 1500)
+    big = _clouds(cuda, [1], 30000)[0]
+    with torch.no_grad():
+        eng = model.engine(calib=small, max_points=40000, margin=1.0)
+        eng.forward(big)
+        assert eng.overflowed()
+        with pytest.raises(RuntimeError):
+            eng.check()
+        out = eng.forward(big, sync=True)  # re-plans with larger capacities
+        assert not eng.overflowed()
+        assert torch.equal(out, model([big]))

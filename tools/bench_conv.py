@@ -39,11 +39,11 @@ def main():
             x = conv(x, _scale=scale, _shift=shift, _relu=True)
     torch.cuda.synchronize()
     reps, rounds = 10, 5
-    splits = [0, 1, 2, 4]
+    splits = [0, 1]  # LCF_OPT_CONV_IMPL: 0 = tile-compacted, 1 = slab
     res = {}
     for r in range(rounds):
         for sp in splits:
-            L.lcf_set_option(0, sp)
+            L.lcf_set_option(1, sp)
             for li, (name, args, pairs) in enumerate(layers):
                 ops.conv_forward(*args)
                 e0 = torch.cuda.Event(enable_timing=True)
@@ -54,9 +54,9 @@ def main():
                 e1.record()
                 e1.synchronize()
                 res.setdefault((li, sp), []).append(e0.elapsed_time(e1) / reps * 1e3)
-    L.lcf_set_option(0, 0)
+    L.lcf_set_option(1, 0)
     tot = {sp: 0.0 for sp in splits}
-    print(f"{'layer':34s} {'pairs':>8s} " + " ".join(f"split{sp}:us/TF" .rjust(16) for sp in splits))
+    print(f"{'layer':34s} {'pairs':>8s} " + " ".join(f"impl{sp}:us/TF" .rjust(16) for sp in splits))
     for li, (name, args, pairs) in enumerate(layers):
         cin, cout = args[5], args[6]
         row = f"{name:34s} {pairs:8d} "
