@@ -29,7 +29,7 @@ F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md "Peak FP32 (matrix)"
 
 
 def dominant_kernel_roofline(model, cloud, reps=20):
-    """Times every launch of the dominant kernel -- cv_fwd_kernel<64,64>, the 64->64 channel
+    """Times every launch of the dominant kernel -- cv_tc_kernel<64,64,32>, the 64->64 channel
     indice_conv (fused gather-GEMM-scatter + BN + ReLU) -- with HIP events on the stream it is
     launched on, after the timed region.  achieved = algorithmic flops per launch
     (2 * pairs * Cin * Cout) / average launch duration."""
@@ -72,7 +72,7 @@ def dominant_kernel_roofline(model, cloud, reps=20):
     achieved = total_flops / n / avg_s / 1e12
     return {"bound": "mfma", "achieved": round(achieved, 3), "peak": F32_MFMA_PEAK_TFLOPS,
             "unit": "TFLOP/s", "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
-            "kernel": "cv_fwd_kernel<64,64>", "launches_per_frame": n,
+            "kernel": "cv_tc_kernel<64,64,32>", "launches_per_frame": n,
             "avg_launch_us": round(avg_s * 1e6, 2),
             "flops_per_launch": round(total_flops / n, 0)}
 

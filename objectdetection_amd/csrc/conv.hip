@@ -300,85 +300,87 @@ epilogue_:
 
 
 // -------------------------------------------------------------------------- tile-compacted fwd
-// Second-generation forward ("tc"): the workgroup owns a tile of 64 output rows.  For every
-// kernel offset it COMPACTS the rows of the tile that have a neighbour at that offset (wave
-// ballot + popcount) and runs the MFMAs only over the resulting ceil(c/16) dense groups of 16
-// gathered rows, instead of over every 16-row slab that has at least one neighbour.  The waves
-// of the workgroup split the output columns, share the gathered A group through LDS and sum
-// each group's 16xCOUT result into an fp32 output tile kept in LDS (every element is owned by
-// exactly one wave and touched in ascending offset order, so the result is deterministic and
-// equals sum_o(dot_o) as the reference's per-offset GEMM + scatter-add computes it).  One
-// barrier per group; W[o] and the next group's rows are prefetched to registers behind the
-// MFMAs of the current group.  MFMA work ~ pairs*Cin*Cout rounded up to 16-row groups per
-// (tile, offset), which is 2-4x less than the slab form on the SECOND rulebooks.
-//
+// Second-generation forward ("tc"): the workgroup owns a tile of TR (32 or 64) output rows.
+// For every kernel offset it COMPACTS the rows of the tile that have a neighbour at that offset
+// (wave ballot + popcount) and runs the MFMAs only over the resulting ceil(c/16) dense groups of
+// 16 gathered rows, instead of over every 16-row slab that has at least one neighbour: MFMA work
+// ~ pairs*Cin*Cout rounded up to 16-row groups per (tile, offset), 2-4x less than the slab form
+// on the SECOND rulebooks.
+//   * One STEP = one active offset: all its groups are gathered into LDS (double buffered; the
+//     next offset's rows are prefetched to registers behind this offset's MFMAs), one barrier
+//     per step.
+//   * The waves of the workgroup split the OUTPUT COLUMNS and share the gathered rows.
+//   * W[o] is NOT staged in LDS: the weight image is stored in fragment order, so each wave
+//     streams its own column slice of W[o] straight from L2 into registers with coalesced
+//     16-byte loads, one offset ahead.
+//   * Each group's 16 x Cout result is added into an fp32 output tile in LDS.  Every element is
+//     owned by exactly one wave and touched in ascending offset order, so the result is
+//     run-to-run deterministic and equals sum_o(dot_o), which is how the reference's per-offset
+//     GEMM + scatter-add sums.
 // Row counts may live on the device (k_dev): the grid is sized by the capacity and workgroups
 // past the actual count exit at once, so the launch needs no host synchronisation.
-#define TC_ROWS 64
-#define TC_DEPTH 4 /* gathered groups in flight per thread */
 
-template <int CIN, int COUT>
+template <int CIN, int COUT, int TR>
 struct TcCfg {
     static constexpr int NW = (COUT / 16 >= 4) ? 4 : COUT / 16; // waves (column split)
     static constexpr int NT = COUT / 16 / NW;                   // column tiles per wave
     static constexpr int THREADS = NW * 64;
+    static constexpr int MAXG = TR / 16;              // groups per offset at most
     static constexpr int KL = CIN / 4;
     static constexpr int VW = KL < 4 ? KL : 4;
     static constexpr int SG = KL / VW;
-    static constexpr int A4 = KL >= 4 ? KL / 4 : 1;
     static constexpr int CH = CIN / 4;                // float4 chunks per gathered row
     static constexpr int ACH = 16 * CH;               // chunks per 16-row group
     static constexpr int APT = (ACH + THREADS - 1) / THREADS;
     static constexpr int ASTR = CIN + 4;              // padded A row stride (floats)
     static constexpr int WELEMS = CIN * COUT;
-    static constexpr int WVEC = WELEMS / 4;
-    static constexpr int WPT = (WVEC + THREADS - 1) / THREADS;
     static constexpr int OSTR = COUT + 4;             // padded output-tile row stride
 };
 
-static size_t tc_lds_bytes(int CIN, int COUT, int kvol, int wbufs)
+static size_t tc_max(size_t a, size_t b) { return a > b ? a : b; }
+
+static size_t tc_lds_bytes(int CIN, int COUT, int TR, int kvol)
 {
-    size_t b = (size_t)wbufs * CIN * COUT * 4;       // W[o] images
-    b += (size_t)2 * 16 * (CIN + 4) * 4;             // A groups (double buffered)
-    b += (size_t)(TC_ROWS + 1) * (COUT + 4) * 4;     // output tile + dump row
-    b += (size_t)TC_ROWS * kvol * 4 * 2;             // neighbour tile + compacted lists
-    b += (size_t)64 * 4 + (size_t)kvol * 4 * 4 + 16; // counts, items, n_items
+    size_t b = (size_t)2 * TR * (CIN + 4) * 4;                            // A rows of one offset
+    b += tc_max((size_t)(TR + 1) * (COUT + 4) * 4, (size_t)TR * kvol * 4); // tile | nbr tile
+    b = (b + 15) & ~(size_t)15;
+    b += (size_t)(TR + 16) * kvol * 4;                                    // item entries
+    b += (size_t)64 * 4 * 3 + 16;                                         // cnt, gbase, soff, n
     return b;
 }
 
 #define TC_THREADS(COUT) (((COUT) / 16 >= 4 ? 4 : (COUT) / 16) * 64)
 
-template <int CIN, int COUT, bool EXACT>
+template <int CIN, int COUT, int TR, bool EXACT>
 __global__ void __launch_bounds__(TC_THREADS(COUT))
 cv_tc_kernel(const float *__restrict__ feat, const float *__restrict__ wimg,
              const int *__restrict__ nbr, int k_cap, const int *__restrict__ k_dev, int kvol,
              int cin, int cout, const float *__restrict__ scale,
-             const float *__restrict__ shift, int relu, float *__restrict__ out, int wbufs)
+             const float *__restrict__ shift, int relu, float *__restrict__ out)
 {
-    using C = TcCfg<CIN, COUT>;
+    using C = TcCfg<CIN, COUT, TR>;
     constexpr int THREADS = C::THREADS, NT = C::NT, KL = C::KL, VW = C::VW, SG = C::SG;
     constexpr int CH = C::CH, ACH = C::ACH, APT = C::APT, ASTR = C::ASTR, OSTR = C::OSTR;
-    constexpr int WELEMS = C::WELEMS, WVEC = C::WVEC, WPT = C::WPT;
-    constexpr bool WFULL = (WVEC % THREADS) == 0;
+    constexpr int WELEMS = C::WELEMS, MAXG = C::MAXG;
     constexpr bool AFULL = (ACH % THREADS) == 0;
+    constexpr int DUMP = TR; // output-tile row that absorbs a group's padding entries
 
-    int k_out = k_cap;
-    if (k_dev) {
-        int kd = *k_dev;
-        k_out = kd < k_cap ? kd : k_cap;
-    }
-    const int row0 = blockIdx.x * TC_ROWS;
+    const int k_out = lcf_count(k_cap, k_dev);
+    const int row0 = blockIdx.x * TR;
     if (row0 >= k_out) return;
 
     extern __shared__ __align__(16) unsigned char smem[];
-    float *wl = reinterpret_cast<float *>(smem);                 // [wbufs][WELEMS]
-    float *al = wl + (size_t)wbufs * WELEMS;                     // [2][16][ASTR]
-    float *ot = al + 2 * 16 * ASTR;                              // [64 + dump row][OSTR]
-    int *nl = reinterpret_cast<int *>(ot + (TC_ROWS + 1) * OSTR); // [64][kvol]
-    unsigned *pl = reinterpret_cast<unsigned *>(nl + TC_ROWS * kvol); // [kvol][64]
-    int *cnt = reinterpret_cast<int *>(pl + TC_ROWS * kvol);     // [64]
-    int *items = cnt + 64;                                       // [kvol*4]
-    int *nitems_p = items + kvol * 4;
+    float *al = reinterpret_cast<float *>(smem);                 // [2][TR][ASTR]
+    float *ot = al + 2 * TR * ASTR;                              // [TR + dump row][OSTR]
+    int *nl = reinterpret_cast<int *>(ot);                       // [TR][kvol], dead before ot lives
+    size_t otb = (size_t)(TR + 1) * OSTR * 4, nlb = (size_t)TR * kvol * 4;
+    size_t off = (size_t)2 * TR * ASTR * 4 + (otb > nlb ? otb : nlb);
+    off = (off + 15) & ~(size_t)15;
+    unsigned *ent = reinterpret_cast<unsigned *>(smem + off);    // [items][16] entries
+    int *cnt = reinterpret_cast<int *>(ent + (TR + 16) * kvol);  // [64] rows per offset
+    int *gbase = cnt + 64;                                       // [64] first item of an offset
+    int *soff = gbase + 64;                                      // [64] offset of step s
+    int *nsteps_p = soff + 64;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -386,119 +388,149 @@ cv_tc_kernel(const float *__restrict__ feat, const float *__restrict__ wimg,
     const int r16 = lane & 15;
     const int q = lane >> 4;
 
-    // ---- neighbour tile -> LDS (coalesced; rows past k_out read as -1), output tile = 0
+    // ---- neighbour tile -> LDS (coalesced; rows past k_out read as -1)
     {
-        const int total = TC_ROWS * kvol;
-        const long long gbase = (long long)row0 * kvol;
+        const int total = TR * kvol;
+        const long long gbase_e = (long long)row0 * kvol;
         const long long glimit = (long long)k_out * kvol;
         for (int e = tid; e < total; e += THREADS) {
             int v = -1;
-            if (gbase + e < glimit) v = nbr ? nbr[gbase + e] : row0 + e; // NULL table: identity
+            if (gbase_e + e < glimit) v = nbr ? nbr[gbase_e + e] : row0 + e; // NULL: identity
             nl[e] = v;
         }
-        for (int e = tid; e < (TC_ROWS + 1) * OSTR; e += THREADS) ot[e] = 0.f;
     }
     __syncthreads();
-    // ---- per offset: compact the rows that have a neighbour (entry = input row << 6 | row)
+    // ---- rows per offset
     for (int o = wave; o < kvol; o += C::NW) {
-        const int id = nl[lane * kvol + o];
-        const bool has = id >= 0;
-        const unsigned long long m = __ballot(has);
-        const int p = __popcll(m & ((1ull << lane) - 1ull));
-        if (has) pl[o * 64 + p] = ((unsigned)id << 6) | (unsigned)lane;
+        const unsigned long long m = __ballot(lane < TR && nl[lane * kvol + o] >= 0);
         if (lane == 0) cnt[o] = __popcll(m);
     }
     __syncthreads();
-    // ---- work items (offset, 16-row group), offsets ascending
+    // ---- steps = active offsets ascending; items = their 16-row groups
     if (wave == 0) {
-        const int ng = lane < kvol ? (cnt[lane] + 15) >> 4 : 0;
-        int incl = ng;
+        const int c = lane < kvol ? cnt[lane] : 0;
+        const int ng = (c + 15) >> 4;
+        int incl = ng, sincl = c > 0 ? 1 : 0;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
             int t = __shfl_up(incl, d, 64);
-            if (lane >= d) incl += t;
+            int u = __shfl_up(sincl, d, 64);
+            if (lane >= d) {
+                incl += t;
+                sincl += u;
+            }
         }
-        const int ex = incl - ng;
-        for (int g = 0; g < ng; ++g) items[ex + g] = lane * 4 + g;
-        if (lane == 63) *nitems_p = incl;
+        gbase[lane] = incl - ng;
+        if (c > 0) soff[sincl - 1] = lane;
+        if (lane == 63) *nsteps_p = sincl;
     }
     __syncthreads();
-    const int n_items = *nitems_p;
+    // ---- item entries: (input row << 7 | output row of the tile); a group's padding entries
+    //      gather a valid row and dump the result
+    for (int o = wave; o < kvol; o += C::NW) {
+        const int id = lane < TR ? nl[lane * kvol + o] : -1;
+        const bool has = id >= 0;
+        const unsigned long long m = __ballot(has);
+        if (m == 0ull) continue;
+        const int c = __popcll(m);
+        const int p = __popcll(m & ((1ull << lane) - 1ull));
+        unsigned *dst = ent + gbase[o] * 16;
+        if (has) dst[p] = ((unsigned)id << 7) | (unsigned)lane;
+        const int first = __shfl(id, __builtin_ctzll(m), 64);
+        const int padded = ((c + 15) >> 4) << 4;
+        if (c + lane < padded) dst[c + lane] = ((unsigned)first << 7) | (unsigned)DUMP;
+    }
+    __syncthreads();
+    for (int e = tid; e < (TR + 1) * OSTR; e += THREADS) ot[e] = 0.f; // nl is dead now
+    const int n_steps = *nsteps_p;
+    __syncthreads();
 
-    constexpr bool exact_in = EXACT; // cin == CIN: rows are whole 16-byte chunks
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
 
-    struct AReg { float4 v[APT]; };
-    struct WReg { float4 v[WPT]; };
+    struct AReg { float4 v[MAXG][APT]; };
+    struct BReg { float b[NT][KL]; };
 
-    auto agather = [&](int o, int g) -> AReg {
+    // rows of the ng groups starting at item i0: thread -> (row r of a group, 16-byte chunk cc)
+    auto agather = [&](int i0, int ng) -> AReg {
         AReg a;
-        const int c = cnt[o];
 #pragma unroll
-        for (int x = 0; x < APT; ++x) {
-            const int ch = tid + x * THREADS;
-            a.v[x] = zero4;
-            if (AFULL || ch < ACH) {
-                const int r = ch / CH, cc = ch % CH;
-                int pos = g * 16 + r;
-                pos = pos < c ? pos : c - 1;
-                const unsigned e = pl[o * 64 + pos];
-                const float *src = feat + (size_t)(e >> 6) * cin + cc * 4;
-                if constexpr (exact_in) {
-                    a.v[x] = *reinterpret_cast<const float4 *>(src);
-                } else {
-                    const int k0 = cc * 4;
-                    float t0 = k0 + 0 < cin ? src[0] : 0.f;
-                    float t1 = k0 + 1 < cin ? src[1] : 0.f;
-                    float t2 = k0 + 2 < cin ? src[2] : 0.f;
-                    float t3 = k0 + 3 < cin ? src[3] : 0.f;
-                    a.v[x] = make_float4(t0, t1, t2, t3);
+        for (int g = 0; g < MAXG; ++g) {
+#pragma unroll
+            for (int x = 0; x < APT; ++x) {
+                const int ch = tid + x * THREADS;
+                a.v[g][x] = zero4;
+                if (g < ng && (AFULL || ch < ACH)) {
+                    const int r = ch / CH, cc = ch % CH;
+                    const unsigned e = ent[(i0 + g) * 16 + r];
+                    const float *src = feat + (size_t)(e >> 7) * cin + cc * 4;
+                    if constexpr (EXACT) {
+                        a.v[g][x] = *reinterpret_cast<const float4 *>(src);
+                    } else {
+                        const int k0 = cc * 4;
+                        float t0 = k0 + 0 < cin ? src[0] : 0.f;
+                        float t1 = k0 + 1 < cin ? src[1] : 0.f;
+                        float t2 = k0 + 2 < cin ? src[2] : 0.f;
+                        float t3 = k0 + 3 < cin ? src[3] : 0.f;
+                        a.v[g][x] = make_float4(t0, t1, t2, t3);
+                    }
                 }
             }
         }
         return a;
     };
-    auto astore = [&](int buf, const AReg &a) {
-        float *dst = al + buf * 16 * ASTR;
+    auto astore = [&](int buf, const AReg &a, int ng) {
+        float *dst = al + buf * TR * ASTR;
 #pragma unroll
-        for (int x = 0; x < APT; ++x) {
-            const int ch = tid + x * THREADS;
-            if (AFULL || ch < ACH) {
-                const int r = ch / CH, cc = ch % CH;
-                *reinterpret_cast<float4 *>(dst + r * ASTR + cc * 4) = a.v[x];
+        for (int g = 0; g < MAXG; ++g) {
+#pragma unroll
+            for (int x = 0; x < APT; ++x) {
+                const int ch = tid + x * THREADS;
+                if (g < ng && (AFULL || ch < ACH)) {
+                    const int r = ch / CH, cc = ch % CH;
+                    *reinterpret_cast<float4 *>(dst + (g * 16 + r) * ASTR + cc * 4) = a.v[g][x];
+                }
             }
         }
     };
-    auto wload = [&](int o) -> WReg {
-        WReg w;
-        const float4 *src = reinterpret_cast<const float4 *>(wimg + (size_t)o * WELEMS);
+    // this wave's column slice of W[o], in fragment order, straight from the image (L2)
+    auto bload = [&](int o) -> BReg {
+        BReg w;
+        const float *wo = wimg + (size_t)o * WELEMS;
 #pragma unroll
-        for (int i = 0; i < WPT; ++i) {
-            const int e = tid + i * THREADS;
-            w.v[i] = src[(WFULL || e < WVEC) ? e : 0];
+        for (int t = 0; t < NT; ++t) {
+            const int tg = wave * NT + t;
+#pragma unroll
+            for (int sg = 0; sg < SG; ++sg) {
+                const float *p = wo + (((tg * SG + sg) * 4 + q) * 16 + r16) * VW;
+                if constexpr (VW == 4) {
+                    float4 x = *reinterpret_cast<const float4 *>(p);
+                    w.b[t][sg * 4 + 0] = x.x;
+                    w.b[t][sg * 4 + 1] = x.y;
+                    w.b[t][sg * 4 + 2] = x.z;
+                    w.b[t][sg * 4 + 3] = x.w;
+                } else if constexpr (VW == 2) {
+                    float2 x = *reinterpret_cast<const float2 *>(p);
+                    w.b[t][0] = x.x;
+                    w.b[t][1] = x.y;
+                } else {
+                    w.b[t][0] = p[0];
+                }
+            }
         }
         return w;
     };
-    auto wstore = [&](int buf, const WReg &w) {
-        float4 *dst = reinterpret_cast<float4 *>(wl + (size_t)buf * WELEMS);
-#pragma unroll
-        for (int i = 0; i < WPT; ++i) {
-            const int e = tid + i * THREADS;
-            if (WFULL || e < WVEC) dst[e] = w.v[i];
-        }
-    };
-    auto compute = [&](int abuf, int wb, int o, int g) {
-        const float *ap = al + abuf * 16 * ASTR + r16 * ASTR + q * KL;
-        // every LDS read of the item is issued before the first MFMA
+    // group g of the step in LDS buffer abuf; item index i names its entries
+    auto compute = [&](int abuf, int g, const BReg &w, int i) {
+        const float *ap = al + (abuf * TR + g * 16 + r16) * ASTR + q * KL;
         float a[KL];
         if constexpr (KL >= 4) {
 #pragma unroll
-            for (int i = 0; i < KL / 4; ++i) {
-                float4 x = reinterpret_cast<const float4 *>(ap)[i];
-                a[4 * i] = x.x;
-                a[4 * i + 1] = x.y;
-                a[4 * i + 2] = x.z;
-                a[4 * i + 3] = x.w;
+            for (int j = 0; j < KL / 4; ++j) {
+                float4 x = reinterpret_cast<const float4 *>(ap)[j];
+                a[4 * j] = x.x;
+                a[4 * j + 1] = x.y;
+                a[4 * j + 2] = x.z;
+                a[4 * j + 3] = x.w;
             }
         } else if constexpr (KL == 2) {
             float2 x = *reinterpret_cast<const float2 *>(ap);
@@ -507,38 +539,10 @@ cv_tc_kernel(const float *__restrict__ feat, const float *__restrict__ wimg,
         } else {
             a[0] = ap[0];
         }
-        const float *wb_p = wl + (size_t)wb * WELEMS;
-        float b[NT][KL];
-#pragma unroll
-        for (int sg = 0; sg < SG; ++sg) {
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const int tg = wave * NT + t;
-                const float *p = wb_p + (((tg * SG + sg) * 4 + q) * 16 + r16) * VW;
-                if constexpr (VW == 4) {
-                    float4 x = *reinterpret_cast<const float4 *>(p);
-                    b[t][sg * 4 + 0] = x.x;
-                    b[t][sg * 4 + 1] = x.y;
-                    b[t][sg * 4 + 2] = x.z;
-                    b[t][sg * 4 + 3] = x.w;
-                } else if constexpr (VW == 2) {
-                    float2 x = *reinterpret_cast<const float2 *>(p);
-                    b[t][0] = x.x;
-                    b[t][1] = x.y;
-                } else {
-                    b[t][0] = p[0];
-                }
-            }
-        }
-        // output rows of this lane's 4 accumulator rows (compacted positions g*16+q*4 .. +3);
-        // positions past the offset's count go to the dump row
-        const int c = cnt[o];
-        const uint4 e4 = *reinterpret_cast<const uint4 *>(pl + o * 64 + g * 16 + q * 4);
-        const int p0 = g * 16 + q * 4;
-        const int orow[4] = {p0 + 0 < c ? (int)(e4.x & 63u) : TC_ROWS,
-                             p0 + 1 < c ? (int)(e4.y & 63u) : TC_ROWS,
-                             p0 + 2 < c ? (int)(e4.z & 63u) : TC_ROWS,
-                             p0 + 3 < c ? (int)(e4.w & 63u) : TC_ROWS};
+        // output rows of this lane's 4 accumulator rows (C/D map: row = q*4 + reg)
+        const uint4 e4 = *reinterpret_cast<const uint4 *>(ent + i * 16 + q * 4);
+        const int orow[4] = {(int)(e4.x & 127u), (int)(e4.y & 127u), (int)(e4.z & 127u),
+                             (int)(e4.w & 127u)};
         f32x4 acc[NT][2];
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
@@ -549,11 +553,9 @@ cv_tc_kernel(const float *__restrict__ feat, const float *__restrict__ wimg,
         for (int s = 0; s < KL; ++s)
 #pragma unroll
             for (int t = 0; t < NT; ++t)
-                acc[t][s & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[t][s], acc[t][s & 1],
-                                                                     0, 0, 0);
-        // sum the group's 16 x (NT*16) block into the output tile: C/D map col = lane&15,
-        // row = q*4 + reg.  Every element has ONE owner wave and is touched once per item, in
-        // item order, so the no-return LDS adds are deterministic.
+                acc[t][s & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], w.b[t][s],
+                                                                     acc[t][s & 1], 0, 0, 0);
+        // tile[orow][cols of this wave] += group result (col = lane&15); exclusive ownership
         float cur[4][NT];
 #pragma unroll
         for (int r = 0; r < 4; ++r)
@@ -568,68 +570,43 @@ cv_tc_kernel(const float *__restrict__ feat, const float *__restrict__ wimg,
                     cur[r][t] + (acc[t][0][r] + acc[t][1][r]);
     };
 
-    if (n_items > 0) {
-        // Software pipeline: the rows of item i+1 .. i+TC_DEPTH are in flight to registers
-        // (ring, statically indexed) while item i computes; W of the next distinct offset is in
-        // flight during the whole current offset.
-        constexpr int D = TC_DEPTH;
-        AReg ring[D];
-        WReg wreg;
-        auto item_o = [&](int i) { return items[i] >> 2; };
-        auto item_g = [&](int i) { return items[i] & 3; };
-        // index of the first item of the next distinct offset after item i (or n_items)
-        auto next_change = [&](int i) {
-            const int oc = item_o(i);
-            int j = i + 1;
-            while (j < n_items && item_o(j) == oc) ++j;
-            return j;
-        };
-        int o = item_o(0), g = item_g(0);
+    if (n_steps > 0) {
+        int o = soff[0];
+        int i0 = gbase[o], ng = (cnt[o] + 15) >> 4;
+        BReg bcur = bload(o);
         {
-            AReg a0 = agather(o, g);
-            WReg w0 = wload(o);
-#pragma unroll
-            for (int s = 1; s <= D; ++s) // item j waits in ring[j % D]
-                if (s < n_items) ring[s % D] = agather(item_o(s), item_g(s));
-            astore(0, a0);
-            wstore(0, w0);
+            AReg a0 = agather(i0, ng);
+            astore(0, a0, ng);
         }
-        int wnext = next_change(0); // first item that needs the W now being prefetched
-        if (wnext < n_items) wreg = wload(item_o(wnext));
         __syncthreads();
-        int wb = 0;
-        for (int i0 = 0; i0 < n_items; i0 += D) {
-#pragma unroll
-            for (int s = 0; s < D; ++s) {
-                const int i = i0 + s;
-                if (i < n_items) {          // workgroup-uniform
-                    compute(i & 1, wb, o, g);
-                    const int in = i + 1;
-                    if (in < n_items) {
-                        const int on = item_o(in), gn = item_g(in);
-                        astore(in & 1, ring[(s + 1) % D]);
-                        if (in + D < n_items)
-                            ring[(s + 1) % D] = agather(item_o(in + D), item_g(in + D));
-                        if (in == wnext) {
-                            wstore(wb ^ 1, wreg);
-                            wnext = next_change(in);
-                            if (wnext < n_items) wreg = wload(item_o(wnext));
-                        }
-                        __syncthreads();
-                        if (on != o) wb ^= 1;
-                        o = on;
-                        g = gn;
-                    }
-                }
+        for (int s = 0; s < n_steps; ++s) {
+            const bool more = s + 1 < n_steps; // workgroup-uniform
+            BReg bnext = bcur;
+            AReg an;
+            int on = o, i0n = i0, ngn = 0;
+            if (more) {
+                on = soff[s + 1];
+                i0n = gbase[on];
+                ngn = (cnt[on] + 15) >> 4;
+                bnext = bload(on);
+                an = agather(i0n, ngn);
             }
+#pragma unroll
+            for (int g = 0; g < MAXG; ++g)
+                if (g < ng) compute(s & 1, g, bcur, i0 + g);
+            if (more) astore((s + 1) & 1, an, ngn);
+            __syncthreads();
+            bcur = bnext;
+            o = on;
+            i0 = i0n;
+            ng = ngn;
         }
-        __syncthreads();
     }
 
     // ---- epilogue: (x*scale + shift), relu, coalesced store of the tile
     if (cout == COUT) {
         constexpr int C4 = COUT / 4;
-        for (int e = tid; e < TC_ROWS * C4; e += THREADS) {
+        for (int e = tid; e < TR * C4; e += THREADS) {
             const int r = e / C4, c4 = e % C4;
             const int row = row0 + r;
             if (row < k_out) {
@@ -650,7 +627,7 @@ cv_tc_kernel(const float *__restrict__ feat, const float *__restrict__ wimg,
             }
         }
     } else {
-        for (int e = tid; e < TC_ROWS * cout; e += THREADS) {
+        for (int e = tid; e < TR * cout; e += THREADS) {
             const int r = e / cout, c = e % cout;
             const int row = row0 + r;
             if (row < k_out) {
@@ -664,35 +641,52 @@ cv_tc_kernel(const float *__restrict__ feat, const float *__restrict__ wimg,
     }
 }
 
-template <int CIN, int COUT>
-static int cv_launch_tc(const float *feat, const float *wimg, const int *nbr, int k_cap,
-                        const int *k_dev, int kvol, int cin, int cout, const float *scale,
-                        const float *shift, int relu, float *out, hipStream_t st)
+static int g_tc_rows = 0; // LCF_OPT_CONV_TILE: 0 = choose from the row count, 32 or 64
+
+template <int CIN, int COUT, int TR>
+static int cv_launch_tc_n(const float *feat, const float *wimg, const int *nbr, int k_cap,
+                          const int *k_dev, int kvol, int cin, int cout, const float *scale,
+                          const float *shift, int relu, float *out, hipStream_t st)
 {
-    using C = TcCfg<CIN, COUT>;
-    int wbufs = kvol == 1 ? 1 : 2;
-    size_t lds = tc_lds_bytes(CIN, COUT, kvol, wbufs);
+    using C = TcCfg<CIN, COUT, TR>;
+    size_t lds = tc_lds_bytes(CIN, COUT, TR, kvol);
     if (lds > 160 * 1024) return LCF_ERR_UNSUPPORTED;
     static size_t lds_set = 0; // per instantiation: largest dynamic LDS size opted into so far
     if (lds > 64 * 1024 && lds > lds_set) {
-        if (hipFuncSetAttribute((const void *)cv_tc_kernel<CIN, COUT, true>,
+        if (hipFuncSetAttribute((const void *)cv_tc_kernel<CIN, COUT, TR, true>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds) != hipSuccess ||
-            hipFuncSetAttribute((const void *)cv_tc_kernel<CIN, COUT, false>,
+            hipFuncSetAttribute((const void *)cv_tc_kernel<CIN, COUT, TR, false>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds) != hipSuccess)
             return LCF_ERR_LAUNCH;
         lds_set = lds;
     }
-    int nb = (k_cap + TC_ROWS - 1) / TC_ROWS;
+    int nb = (k_cap + TR - 1) / TR;
     if (cin == CIN)
-        cv_tc_kernel<CIN, COUT, true><<<nb, C::THREADS, lds, st>>>(
-            feat, wimg, nbr, k_cap, k_dev, kvol, cin, cout, scale, shift, relu, out, wbufs);
+        cv_tc_kernel<CIN, COUT, TR, true><<<nb, C::THREADS, lds, st>>>(
+            feat, wimg, nbr, k_cap, k_dev, kvol, cin, cout, scale, shift, relu, out);
     else
-        cv_tc_kernel<CIN, COUT, false><<<nb, C::THREADS, lds, st>>>(
-            feat, wimg, nbr, k_cap, k_dev, kvol, cin, cout, scale, shift, relu, out, wbufs);
+        cv_tc_kernel<CIN, COUT, TR, false><<<nb, C::THREADS, lds, st>>>(
+            feat, wimg, nbr, k_cap, k_dev, kvol, cin, cout, scale, shift, relu, out);
     LCF_CHECK_LAUNCH();
     return LCF_OK;
+}
+
+template <int CIN, int COUT>
+static int cv_launch_tc(const float *feat, const float *wimg, const int *nbr, int k_cap,
+                        const int *k_dev, int kvol, int cin, int cout, const float *scale,
+                        const float *shift, int relu, float *out, hipStream_t st)
+{
+    // 64-row tiles halve the W traffic; 32-row tiles double the number of workgroups.
+    int tr = 32; // measured: 32-row tiles win on every SECOND layer (more, shorter workgroups)
+    if (g_tc_rows == 32 || g_tc_rows == 64) tr = g_tc_rows;
+    if (tr == 64 && tc_lds_bytes(CIN, COUT, 64, kvol) > 160 * 1024) tr = 32;
+    if (tr == 64)
+        return cv_launch_tc_n<CIN, COUT, 64>(feat, wimg, nbr, k_cap, k_dev, kvol, cin, cout,
+                                             scale, shift, relu, out, st);
+    return cv_launch_tc_n<CIN, COUT, 32>(feat, wimg, nbr, k_cap, k_dev, kvol, cin, cout, scale,
+                                         shift, relu, out, st);
 }
 
 // -------------------------------------------------------------------------- wgrad
@@ -808,7 +802,7 @@ static int cv_launch_fwd_n(const float *feat, const float *wimg, const int *nbr,
 
 // Tuning knob (lcf_set_option(LCF_OPT_CONV_SPLIT, 1|2|4)); 0 = pick by size.
 static int g_conv_split = 0;
-static int g_conv_impl = 1; // 1 = slab form (default), 0 = tile-compacted everywhere
+static int g_conv_impl = 0; // 0 = choose per shape, 1 = slab form, 2 = tile-compacted
 static int cv_split_override() { return g_conv_split; }
 
 extern "C" int lcf_set_option(int option, int value)
@@ -819,8 +813,13 @@ extern "C" int lcf_set_option(int option, int value)
         return LCF_OK;
     }
     if (option == LCF_OPT_CONV_IMPL) {
-        if (value != 0 && value != 1) return LCF_ERR_ARG;
+        if (value < 0 || value > 2) return LCF_ERR_ARG;
         g_conv_impl = value;
+        return LCF_OK;
+    }
+    if (option == LCF_OPT_CONV_TILE) {
+        if (value != 0 && value != 32 && value != 64) return LCF_ERR_ARG;
+        g_tc_rows = value;
         return LCF_OK;
     }
     return LCF_ERR_ARG;
@@ -898,7 +897,11 @@ extern "C" int lcf_indice_conv_fwd(const float *feat, const float *wimg, const i
     if (CIN < 0 || COUT < 0) return LCF_ERR_UNSUPPORTED;
     if (k_out == 0) return LCF_OK;
     hipStream_t st = (hipStream_t)stream;
-    if (g_conv_impl == 1 && nbr && CIN * COUT <= 8192) {
+    // narrow layers (one column tile = one wave per workgroup, or < 32 inputs) stay on the slab form
+    const bool slab_ok = nbr && CIN * COUT <= 8192;
+    const bool use_slab = g_conv_impl == 1 ? slab_ok : (g_conv_impl == 2 ? false
+                                                                        : slab_ok && (COUT < 32 || CIN < 32));
+    if (use_slab) {
         CV_DISPATCH(cv_launch_fwd, feat, wimg, nbr, k_out, k_out_dev, kvol, cin, cout, scale,
                     shift, relu, out, st);
     }

@@ -39,11 +39,12 @@ def main():
             x = conv(x, _scale=scale, _shift=shift, _relu=True)
     torch.cuda.synchronize()
     reps, rounds = 10, 5
-    splits = [0, 1]  # LCF_OPT_CONV_IMPL: 0 = tile-compacted, 1 = slab
+    splits = [1, 32, 64]  # 1 = slab form; 32 / 64 = tile-compacted with that many rows per tile
     res = {}
     for r in range(rounds):
         for sp in splits:
-            L.lcf_set_option(1, sp)
+            L.lcf_set_option(1, 1 if sp == 1 else 2)
+            L.lcf_set_option(2, 0 if sp == 1 else sp)
             for li, (name, args, pairs) in enumerate(layers):
                 ops.conv_forward(*args)
                 e0 = torch.cuda.Event(enable_timing=True)
@@ -55,6 +56,7 @@ def main():
                 e1.synchronize()
                 res.setdefault((li, sp), []).append(e0.elapsed_time(e1) / reps * 1e3)
     L.lcf_set_option(1, 0)
+    L.lcf_set_option(2, 0)
     tot = {sp: 0.0 for sp in splits}
     print(f"{'layer':34s} {'pairs':>8s} " + " ".join(f"impl{sp}:us/TF" .rjust(16) for sp in splits))
     for li, (name, args, pairs) in enumerate(layers):
