@@ -180,6 +180,17 @@ int lcf_vfe_augment(const float *voxels, const int *num, int k, const int *k_dev
 int lcf_vfe_pool(const float *x, const int *num, int k, const int *k_dev, int t, int u,
                  const float *scale, const float *shift, int mode, float *out, void *stream);
 
+/* VoxelFeatureExtractor.forward (voxel_encoder.py:113-140) in ONE persistent kernel for the
+ * shipped shape: f (+3 mean-centred) <= 8 inputs, VFE layers of u1 = 16 and u2 = 64 units, final
+ * Linear of u3 = 128 (num_filters [32,128]); any other shape, or t too large for the group to
+ * stay in LDS, returns LCF_ERR_UNSUPPORTED and the caller uses the layer-by-layer entry points.
+ * w?img: lcf_weight_image of the Linear weights as [1,in,out]; sc?/sh?: eval-mode BatchNorm in
+ * affine form (NULL = identity / bias only).  out [k,128]. */
+int lcf_vfe_fused(const float *voxels, const int *num, int k, const int *k_dev, int t, int f,
+                  int u1, int u2, int u3, const float *w1img, const float *sc1, const float *sh1,
+                  const float *w2img, const float *sc2, const float *sh2, const float *w3img,
+                  const float *sc3, const float *sh3, float *out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -57,6 +57,8 @@ SYMBOLS = {
                                 c_void_p]),
     "lcf_vfe_pool": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p,
                              c_void_p, c_int, c_void_p, c_void_p]),
+    "lcf_vfe_fused": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int,
+                              c_int] + [c_void_p] * 11),
 }
 
 _lib = None

@@ -1,0 +1,274 @@
+// vfe_fused.hip -- VoxelFeatureExtractor.forward (second/pytorch/models/voxel_encoder.py:113-140)
+// as ONE persistent kernel for the shipped shape: F(+3) <= 8 point features -> VFE(16|32) ->
+// VFE(64|128) -> Linear 128 + BN + ReLU -> masked max over the T points of a voxel.
+//
+// A workgroup (4 waves) walks groups of 16 voxels = 16*T point rows.  The three weight matrices
+// never touch LDS: each wave keeps the fragments of ITS output columns in registers for the whole
+// kernel (W3: 2 column tiles x 32 k = 64 VGPRs, W2: 8, W1: 2), loaded once from the MFMA weight
+// images (same image layout as the sparse conv, conv.hip).  Activations of the group live in LDS
+// only; HBM sees the voxel rows once (coalesced) and the [K,128] result once.
+//   stage 0  rows -> LDS, per-voxel mean (t ascending, / num as the reference), augment to 8 wide
+//   stage 1  X0[R,8]  x W1 -> relu(bn) -> max over ALL T rows (LDS integer max: values >= 0)
+//            -> X1 = [y, max] * mask                                   (VFELayer :65-80, mask :130)
+//   stage 2  X1[R,32] x W2 -> same -> X2 = [y, max] * mask
+//   stage 3  X2[R,128] x W3 -> relu(bn) * mask -> max over T -> out     (:133-139)
+// v_mfma_f32_16x16x4_f32 is an exact fp32 FMA chain, so results equal the layer-by-layer path
+// up to fp32 summation order.
+#include "common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define VF_V 16       /* voxels per group */
+#define VF_THREADS 256
+#define VF_U1 16
+#define VF_U2 64
+#define VF_U3 128
+#define VF_S0 12      /* X0 row stride (8 + pad) */
+#define VF_S1 36      /* X1 row stride (32 + pad) */
+#define VF_S2 132     /* X2 row stride (128 + pad) */
+
+// B fragment (fragment-ordered image, see cv_img_pos in conv.hip) of column tile tg:
+// KL floats per lane; lane quarter q holds k in [q*KL, (q+1)*KL)
+template <int CIN, int KL>
+__device__ __forceinline__ void vf_bload(const float *__restrict__ img, int tg, int q, int r16,
+                                         float *b)
+{
+    constexpr int VW = KL < 4 ? KL : 4;
+    constexpr int SG = KL / VW;
+#pragma unroll
+    for (int sg = 0; sg < SG; ++sg) {
+        const float *p = img + (((tg * SG + sg) * 4 + q) * 16 + r16) * VW;
+        if constexpr (VW == 4) {
+            float4 x = *reinterpret_cast<const float4 *>(p);
+            b[sg * 4 + 0] = x.x;
+            b[sg * 4 + 1] = x.y;
+            b[sg * 4 + 2] = x.z;
+            b[sg * 4 + 3] = x.w;
+        } else {
+            float2 x = *reinterpret_cast<const float2 *>(p);
+            b[0] = x.x;
+            b[1] = x.y;
+        }
+    }
+}
+
+template <int KL>
+__device__ __forceinline__ void vf_aload(const float *row, float *a)
+{
+    if constexpr (KL >= 4) {
+#pragma unroll
+        for (int j = 0; j < KL / 4; ++j) {
+            float4 x = reinterpret_cast<const float4 *>(row)[j];
+            a[4 * j] = x.x;
+            a[4 * j + 1] = x.y;
+            a[4 * j + 2] = x.z;
+            a[4 * j + 3] = x.w;
+        }
+    } else {
+        float2 x = *reinterpret_cast<const float2 *>(row);
+        a[0] = x.x;
+        a[1] = x.y;
+    }
+}
+
+template <int KL>
+__device__ __forceinline__ f32x4 vf_dot(const float *a, const float *b)
+{
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < KL; ++s) {
+        if (s & 1)
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[s], acc1, 0, 0, 0);
+        else
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[s], acc0, 0, 0, 0);
+    }
+    return acc0 + acc1;
+}
+
+__global__ void __launch_bounds__(VF_THREADS)
+vfe_fused_kernel(const float *__restrict__ voxels, const int *__restrict__ num, int k_cap,
+                 const int *__restrict__ k_dev, int T, int F, const float *__restrict__ w1,
+                 const float *__restrict__ sc1, const float *__restrict__ sh1,
+                 const float *__restrict__ w2, const float *__restrict__ sc2,
+                 const float *__restrict__ sh2, const float *__restrict__ w3,
+                 const float *__restrict__ sc3, const float *__restrict__ sh3,
+                 float *__restrict__ out)
+{
+    const int k = lcf_count(k_cap, k_dev);
+    const int ngroups = (k + VF_V - 1) / VF_V;
+    if ((int)blockIdx.x >= ngroups) return;
+    const int R = VF_V * T;   // rows per group (multiple of 16)
+    const int NRT = T;        // 16-row tiles per group
+
+    extern __shared__ __align__(16) unsigned char smem[];
+    float *X0 = reinterpret_cast<float *>(smem);     // [R][VF_S0]
+    float *X1 = X0 + R * VF_S0;                      // [R][VF_S1]
+    float *X2 = X1 + R * VF_S1;                      // [R][VF_S2]
+    int *P1 = reinterpret_cast<int *>(X2 + R * VF_S2); // [16][16]  per-voxel maxima (float bits)
+    int *P2 = P1 + VF_V * VF_U1;                     // [16][64]
+    int *P3 = P2 + VF_V * VF_U2;                     // [16][128]
+    int *nv = P3 + VF_V * VF_U3;                     // [16] points per voxel
+    unsigned short *rv = reinterpret_cast<unsigned short *>(nv + VF_V); // [R] voxel | t << 8
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int r16 = lane & 15;
+    const int q = lane >> 4;
+
+    // ---- weights -> registers, once
+    float b1[2], b2[8], b3[2][32];
+    vf_bload<8, 2>(w1, 0, q, r16, b1);
+    vf_bload<32, 8>(w2, wave, q, r16, b2);
+    vf_bload<128, 32>(w3, 2 * wave, q, r16, b3[0]);
+    vf_bload<128, 32>(w3, 2 * wave + 1, q, r16, b3[1]);
+    const float s1 = sc1 ? sc1[r16] : 1.f, h1 = sh1 ? sh1[r16] : 0.f;
+    const float s2 = sc2 ? sc2[wave * 16 + r16] : 1.f, h2 = sh2 ? sh2[wave * 16 + r16] : 0.f;
+    float s3[2], h3[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        s3[c] = sc3 ? sc3[(2 * wave + c) * 16 + r16] : 1.f;
+        h3[c] = sh3 ? sh3[(2 * wave + c) * 16 + r16] : 0.f;
+    }
+    for (int r = tid; r < R; r += VF_THREADS) rv[r] = (unsigned short)((r / T) | ((r % T) << 8));
+
+    for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+        const int v0 = grp * VF_V;
+        __syncthreads(); // previous group's LDS reads are done (and rv is visible)
+        // ---- stage 0a: rows -> X0[:, 0:F] (zero for voxels past k), maxima = 0
+        for (int r = tid; r < R; r += VF_THREADS) {
+            const int v = v0 + (rv[r] & 255);
+            float *d = X0 + r * VF_S0;
+            const float *src = voxels + ((size_t)v0 * T + r) * F;
+            for (int e = 0; e < 8; ++e) d[e] = (v < k && e < F) ? src[e] : 0.f;
+        }
+        if (tid < VF_V) nv[tid] = (v0 + tid < k) ? num[v0 + tid] : 0;
+        for (int e = tid; e < VF_V * (VF_U1 + VF_U2 + VF_U3); e += VF_THREADS) P1[e] = 0;
+        __syncthreads();
+        // ---- stage 0b: centre xyz on the voxel mean: X0[:, F:F+3]
+        for (int r = tid; r < R; r += VF_THREADS) {
+            const int vl = rv[r] & 255;
+            const float n = (float)(nv[vl] > 0 ? nv[vl] : 1); // voxels past k: keep it finite
+            const float *base = X0 + vl * T * VF_S0;
+            float *d = X0 + r * VF_S0;
+#pragma unroll
+            for (int e = 0; e < 3; ++e) {
+                float s = 0.f;
+                for (int i = 0; i < T; ++i) s += base[i * VF_S0 + e];
+                d[F + e] = d[e] - __fdiv_rn(s, n);
+            }
+        }
+        __syncthreads();
+        // ---- stage 1: [R,8] x W1[8,16]; row tiles round-robin over the waves
+        for (int rt = wave; rt < NRT; rt += 4) {
+            float a[2];
+            vf_aload<2>(X0 + (rt * 16 + r16) * VF_S0 + q * 2, a);
+            f32x4 acc = vf_dot<2>(a, b1);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = rt * 16 + q * 4 + r;
+                const float y = fmaxf(acc[r] * s1 + h1, 0.f);
+                X1[row * VF_S1 + r16] = y;
+                atomicMax(&P1[(rv[row] & 255) * VF_U1 + r16], __float_as_int(y));
+            }
+        }
+        __syncthreads();
+        for (int e = tid; e < R * VF_U1; e += VF_THREADS) {
+            const int row = e / VF_U1, c = e % VF_U1;
+            const int vl = rv[row] & 255, t = rv[row] >> 8;
+            const float m = t < nv[vl] ? 1.f : 0.f;
+            X1[row * VF_S1 + c] *= m;
+            X1[row * VF_S1 + VF_U1 + c] = __int_as_float(P1[vl * VF_U1 + c]) * m;
+        }
+        __syncthreads();
+        // ---- stage 2: [R,32] x W2[32,64]; wave = column tile
+        for (int rt = 0; rt < NRT; ++rt) {
+            float a[8];
+            vf_aload<8>(X1 + (rt * 16 + r16) * VF_S1 + q * 8, a);
+            f32x4 acc = vf_dot<8>(a, b2);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = rt * 16 + q * 4 + r;
+                const float y = fmaxf(acc[r] * s2 + h2, 0.f);
+                X2[row * VF_S2 + wave * 16 + r16] = y;
+                atomicMax(&P2[(rv[row] & 255) * VF_U2 + wave * 16 + r16], __float_as_int(y));
+            }
+        }
+        __syncthreads();
+        for (int e = tid; e < R * VF_U2; e += VF_THREADS) {
+            const int row = e / VF_U2, c = e % VF_U2;
+            const int vl = rv[row] & 255, t = rv[row] >> 8;
+            const float m = t < nv[vl] ? 1.f : 0.f;
+            X2[row * VF_S2 + c] *= m;
+            X2[row * VF_S2 + VF_U2 + c] = __int_as_float(P2[vl * VF_U2 + c]) * m;
+        }
+        __syncthreads();
+        // ---- stage 3: [R,128] x W3[128,128]; wave = 2 column tiles; masked max over T
+        for (int rt = 0; rt < NRT; ++rt) {
+            float a[32];
+            vf_aload<32>(X2 + (rt * 16 + r16) * VF_S2 + q * 32, a);
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                f32x4 acc = vf_dot<32>(a, b3[c]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = rt * 16 + q * 4 + r;
+                    const int vl = rv[row] & 255, t = rv[row] >> 8;
+                    float y = fmaxf(acc[r] * s3[c] + h3[c], 0.f);
+                    y = t < nv[vl] ? y : 0.f;
+                    atomicMax(&P3[vl * VF_U3 + (2 * wave + c) * 16 + r16], __float_as_int(y));
+                }
+            }
+        }
+        __syncthreads();
+        for (int e = tid; e < VF_V * VF_U3 / 4; e += VF_THREADS) {
+            const int vl = e / (VF_U3 / 4), c4 = e % (VF_U3 / 4);
+            if (v0 + vl < k)
+                reinterpret_cast<float4 *>(out + (size_t)(v0 + vl) * VF_U3)[c4] =
+                    *reinterpret_cast<const float4 *>(P3 + vl * VF_U3 + c4 * 4);
+        }
+    }
+}
+
+static size_t vf_lds_bytes(int T)
+{
+    size_t R = (size_t)VF_V * T;
+    size_t b = R * (VF_S0 + VF_S1 + VF_S2) * 4;
+    b += (size_t)VF_V * (VF_U1 + VF_U2 + VF_U3) * 4 + VF_V * 4 + R * 2 + 16;
+    return b;
+}
+
+extern "C" int lcf_vfe_fused(const float *voxels, const int *num, int k, const int *k_dev, int t,
+                             int f, int u1, int u2, int u3, const float *w1img, const float *sc1,
+                             const float *sh1, const float *w2img, const float *sc2,
+                             const float *sh2, const float *w3img, const float *sc3,
+                             const float *sh3, float *out, void *stream)
+{
+    if (k < 0 || t <= 0 || f < 3 || !w1img || !w2img || !w3img ||
+        (k > 0 && (!voxels || !num || !out)))
+        return LCF_ERR_ARG;
+    if (u1 != VF_U1 || u2 != VF_U2 || u3 != VF_U3 || f + 3 > 8 || t > 255) return LCF_ERR_UNSUPPORTED;
+    size_t lds = vf_lds_bytes(t);
+    if (lds > 160 * 1024) return LCF_ERR_UNSUPPORTED; // T too large: use the layer-by-layer path
+    if (((uintptr_t)out & 15) || ((uintptr_t)w1img & 15) || ((uintptr_t)w2img & 15) ||
+        ((uintptr_t)w3img & 15))
+        return LCF_ERR_ARG;
+    if (k == 0) return LCF_OK;
+    static size_t lds_set = 0;
+    if (lds > 64 * 1024 && lds > lds_set) {
+        if (hipFuncSetAttribute((const void *)vfe_fused_kernel,
+                                hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds) != hipSuccess)
+            return LCF_ERR_LAUNCH;
+        lds_set = lds;
+    }
+    int ngroups = (k + VF_V - 1) / VF_V;
+    int per_cu = (int)((160 * 1024) / lds);
+    if (per_cu < 1) per_cu = 1;
+    if (per_cu > 2) per_cu = 2;
+    int nb = ngroups < 256 * per_cu ? ngroups : 256 * per_cu;
+    vfe_fused_kernel<<<nb, VF_THREADS, lds, (hipStream_t)stream>>>(
+        voxels, num, k, k_dev, t, f, w1img, sc1, sh1, w2img, sc2, sh2, w3img, sc3, sh3, out);
+    LCF_CHECK_LAUNCH();
+    return LCF_OK;
+}

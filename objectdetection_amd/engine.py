@@ -171,8 +171,15 @@ class FrameEngine:
         self.vox_ws = E(max(L.lcf_voxelize_workspace_bytes(self.max_points, T), 256),
                         dtype=torch.uint8)
         self.flags = torch.zeros(max(self.n_strided, 1), dtype=i32, device=dev)
+        self.vfe_fused = False
         if self.vfe_kind == "vfe":
             (_, c0, u1, _, _), (_, _, u2, _, _), (_, _, u3, _, _) = self.lin
+            probe = ops.vfe_fused(torch.zeros((1, T, F), device=dev),
+                                  torch.ones(1, dtype=i32, device=dev), self.lin)
+            self.vfe_fused = probe is not None
+        if self.vfe_kind == "vfe" and self.vfe_fused:
+            self.feat0 = E(MV, u3)
+        elif self.vfe_kind == "vfe":
             self.kt = torch.zeros(1, dtype=i32, device=dev)
             self.aug = E(MV, T, c0)
             self.x1, self.p1 = E(MV * T, u1), E(MV, T, 2 * u1)
@@ -233,7 +240,12 @@ class FrameEngine:
                              P(self.coors), P(self.num), P(self.vnum), P(self.vox_ws),
                              self.vox_ws.numel(), st))
         kd = self.vnum
-        if self.vfe_kind == "vfe":
+        if self.vfe_kind == "vfe" and self.vfe_fused:
+            (w1, c0, u1, s1, h1), (w2, _, u2, s2, h2), (w3, _, u3, s3, h3) = self.lin
+            check(L.lcf_vfe_fused(P(self.voxels), P(self.num), MV, P(kd), T, F, u1, u2, u3,
+                                  P(w1), P(s1), P(h1), P(w2), P(s2), P(h2), P(w3), P(s3), P(h3),
+                                  P(self.feat0), st))
+        elif self.vfe_kind == "vfe":
             torch.mul(self.vnum, T, out=self.kt)
             (w1, c0, u1, s1, h1), (w2, _, u2, s2, h2), (w3, _, u3, s3, h3) = self.lin
             check(L.lcf_vfe_augment(P(self.voxels), P(self.num), MV, P(kd), T, F, P(self.aug), st))

@@ -347,3 +347,22 @@ def vfe_pool(x, num_points, scale, shift, mode):
     check(_lib.lib().lcf_vfe_pool(_ptr(x), _ptr(num_points.int().contiguous()), k, None, t, u,
                                   _ptr(scale), _ptr(shift), int(mode), _ptr(out), _stream()))
     return out
+
+
+def vfe_fused(voxels, num_points, lin, k_dev=None, out=None):
+    """Whole VoxelFeatureExtractor in one kernel.  lin = [(wimg, cin, cout, scale, shift)] * 3
+    (weight images of the three Linear layers + folded BatchNorm).  Returns None when the shape
+    is outside what the fused kernel is built for (caller falls back to the layer kernels)."""
+    _need_cuda(voxels, num_points)
+    v = voxels.contiguous()
+    k, t, f = v.shape
+    (w1, c0, u1, s1, h1), (w2, _, u2, s2, h2), (w3, _, u3, s3, h3) = lin
+    if out is None:
+        out = torch.empty((k, u3), dtype=torch.float32, device=v.device)
+    rc = _lib.lib().lcf_vfe_fused(_ptr(v), _ptr(num_points), k, _ptr(k_dev), t, f, u1, u2, u3,
+                                  _ptr(w1), _ptr(s1), _ptr(h1), _ptr(w2), _ptr(s2), _ptr(h2),
+                                  _ptr(w3), _ptr(s3), _ptr(h3), _ptr(out), _stream())
+    if rc == -3:
+        return None
+    check(rc)
+    return out

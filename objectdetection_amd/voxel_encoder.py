@@ -114,8 +114,38 @@ class _VFEBase(nn.Module):
             return torch.cat([features, features_relative, points_dist], dim=-1)
         return torch.cat([features, features_relative], dim=-1)
 
+    def _fused_lin(self, layers):
+        """[(weight image, cin, cout, scale, shift)] of the three Linear layers, cached until a
+        parameter or BatchNorm statistic changes."""
+        mods = [(l.linear, l.norm) for l in layers] + [(self.linear, self.norm)]
+        tensors = []
+        for lin, norm in mods:
+            tensors += [lin.weight, lin.bias]
+            if isinstance(norm, nn.BatchNorm1d):
+                tensors += [norm.weight, norm.bias, norm.running_mean, norm.running_var]
+        tag = tuple((t.data_ptr(), t._version) if t is not None else None for t in tensors)
+        cache = getattr(self, "_fused_cache", None)
+        if cache is None or cache[0] != tag:
+            out = []
+            for lin, norm in mods:
+                w = lin.weight.detach().float().t().contiguous()  # [in, out]
+                cin, cout = w.shape
+                scale, shift = _affine(norm, cout, w.device)
+                if lin.bias is not None:
+                    b = lin.bias.detach().float()
+                    shift = (b * scale + shift) if scale is not None else b
+                out.append((ops.weight_image(w.view(1, cin, cout)), cin, cout, scale,
+                            None if shift is None else shift.contiguous()))
+            cache = (tag, out)
+            object.__setattr__(self, "_fused_cache", cache)
+        return cache[1]
+
     def _forward_layers(self, layers, features, num_voxels):
         if _fast_path(self, features) and not self._with_distance and features.shape[0] > 0:
+            if len(layers) == 2 and num_voxels.dtype == torch.int32:
+                out = ops.vfe_fused(features, num_voxels.contiguous(), self._fused_lin(layers))
+                if out is not None:
+                    return out
             x = ops.vfe_augment(features, num_voxels)
             for vfe in layers:
                 x = vfe.forward_masked(x, num_voxels)

@@ -147,3 +147,34 @@ def test_vfe_hip_path_matches_reference_golden(cuda):
         with torch.no_grad():
             got = m(vox, num, None).cpu().numpy()
         assert rel_err(got, G[f"{tag}/eval"]) < 2e-5, tag
+
+
+def test_vfe_fused_kernel_matches_layer_kernels(cuda):
+    """lcf_vfe_fused (one persistent kernel) vs the layer-by-layer streaming kernels + torch
+    Linear, ragged sizes, device-side voxel count; T too large for LDS falls back."""
+    from objectdetection_amd import ops, voxel_encoder as ve
+    torch.manual_seed(5)
+    m = randomize_(ve.VoxelFeatureExtractor(4, True, [32, 128]).eval(), 7).to(cuda)
+    for k, t in [(1, 5), (17, 5), (5003, 5), (333, 8), (40, 1)]:
+        num = torch.randint(1, t + 1, (k,), dtype=torch.int32, device=cuda)
+        vox = torch.randn(k, t, 4, device=cuda)
+        vox = vox * (torch.arange(t, device=cuda)[None, :, None] < num[:, None, None])
+        with torch.no_grad():
+            lin = m._fused_lin([m.vfe1, m.vfe2])
+            fused = ops.vfe_fused(vox, num, lin)
+            assert fused is not None
+            x = ops.vfe_augment(vox, num)
+            for layer in (m.vfe1, m.vfe2):
+                x = layer.forward_masked(x, num)
+            x = m.linear(x)
+            sc, sh = ve._affine(m.norm, 128, x.device)
+            layered = ops.vfe_pool(x, num, sc, sh, 1)
+        assert rel_err(fused.cpu().numpy(), layered.cpu().numpy()) < 1e-5, (k, t)
+        # device-side count: only the first kd voxels are written
+        kd = max(1, k // 2)
+        out = torch.full((k, 128), -1.0, device=cuda)
+        ops.vfe_fused(vox, num, lin, k_dev=torch.tensor([kd], dtype=torch.int32, device=cuda),
+                      out=out)
+        assert torch.equal(out[:kd], fused[:kd]) and bool((out[kd:] == -1).all())
+    big_t = torch.zeros(4, 35, 4, device=cuda)
+    assert ops.vfe_fused(big_t, torch.ones(4, dtype=torch.int32, device=cuda), lin) is None
