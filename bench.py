@@ -70,8 +70,15 @@ def dominant_kernel_roofline(model, cloud, reps=20):
         n += 1
     avg_s = total_ms / n * 1e-3
     achieved = total_flops / n / avg_s / 1e12
+    traffic = None  # HBM bytes per launch from the committed PMC passes (tools/pmc_summary.py)
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_dominant_kernel.json")) as fh:
+            traffic = json.load(fh)["hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        pass
     return {"bound": "mfma", "achieved": round(achieved, 3), "peak": F32_MFMA_PEAK_TFLOPS,
-            "unit": "TFLOP/s", "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+            "unit": "TFLOP/s", "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4),
+            "traffic": traffic,
             "kernel": "cv_tc_kernel<64,64,32>", "launches_per_frame": n,
             "avg_launch_us": round(avg_s * 1e6, 2),
             "flops_per_launch": round(total_flops / n, 0)}
