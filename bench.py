@@ -97,6 +97,37 @@ def cpu_baseline(model_name, cloud_np, budget_s):
                       f"{threads} threads), not the original binaries"}
 
 
+def train_measurement(args, dev, rank, world, dist, barrier):
+    """BASELINE.json configs[2]/[3]: training step (VFE + sparse middle fwd/dgrad/wgrad + RPNV2 +
+    loss + optimizer) on `train_batch` frames per rank, scene-sharded, ONE flat gradient
+    all-reduce per step over RCCL when world > 1.  Reported beside the headline metric."""
+    from objectdetection_amd.train import TrainStep
+    step = TrainStep(dev, args.model, seed=0)
+    b = args.train_batch
+    frames = [torch.from_numpy(synth.vkitti_frame(1000 + rank * 2 * b + i, args.points)).to(dev)
+              for i in range(2 * b)]
+    batches = [frames[:b], frames[b:]]
+    for i in range(3):
+        step(batches[i % 2])
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.train_steps):
+        loss = step(batches[i % 2])
+    barrier()
+    el = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([el], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    nparams = sum(p.numel() for p in step.net.parameters())
+    return {"metric": "frames/s training step (VFE + sparse middle fwd/dgrad/wgrad + RPNV2)",
+            "value": round(world * b * args.train_steps / el, 2), "unit": "frames/s",
+            "ms_per_step": round(el / args.train_steps * 1e3, 2), "steps": args.train_steps,
+            "global_batch": world * b, "dtype": "f32", "scaling": "weak",
+            "allreduce_bytes": 4 * nparams if world > 1 else 0,
+            "loss": round(float(loss), 4)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -107,6 +138,9 @@ def main():
     ap.add_argument("--frames", type=int, default=8, help="distinct synthetic frames cycled")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--train-steps", type=int, default=10,
+                    help="timed training steps of the second measurement (0 = skip it)")
+    ap.add_argument("--train-batch", type=int, default=8, help="frames per rank per step")
     ap.add_argument("--eager", action="store_true",
                     help="module-by-module path (spconv API, host syncs) instead of the "
                          "graph-captured FrameEngine")
@@ -161,6 +195,9 @@ def main():
         roof = dominant_kernel_roofline(model, clouds[0]) if rank == 0 and args.model != "M3" \
             else None
 
+    train = train_measurement(args, dev, rank, world, dist, barrier) if args.train_steps > 0 \
+        and args.model != "M3" else None
+
     if rank == 0:
         fps = world * args.steps / elapsed
         line = {
@@ -179,6 +216,8 @@ def main():
         }
         if roof is not None:
             line["roofline"] = roof
+        if train is not None:
+            line["train"] = train
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.model, clouds_np[0], args.cpu_budget)
         print(json.dumps(line), flush=True)

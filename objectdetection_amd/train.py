@@ -1,0 +1,66 @@
+"""One training step of the detector's GPU part with the reference's shapes: voxelize -> VFE ->
+sparse middle (fwd, dgrad, wgrad on liblcf) -> RPNV2 -> loss -> backward -> one flat gradient
+all-reduce -> optimizer (second/pytorch/train.py:316-343 minus the data pipeline; BASELINE.json
+configs[2] and [3]).  Targets are synthetic (no dataset here): the step exercises the same
+kernels and the same gradient volume as the real loss (sigmoid focal classification
+second/pytorch/core/losses.py + smooth-L1 box regression)."""
+import torch
+from torch import nn
+from torch.nn import functional as F
+
+from .dist import FlatGradAllReduce
+from .frontend import SparseFrontEnd, randomize_
+from .rpn import RPNV2
+
+
+class Detector(nn.Module):
+    def __init__(self, model="M2", max_voxels=17000):  # 17000: training cap (base.yaml:118)
+        super().__init__()
+        self.frontend = SparseFrontEnd(model, max_voxels=max_voxels)
+        self.rpn = RPNV2(num_input_features=128)
+
+    def forward(self, clouds):
+        return self.rpn(self.frontend(clouds))
+
+
+def synthetic_loss(preds, gen):
+    """Focal-style classification + smooth-L1 box + direction losses against random targets of
+    the reference's shapes (cls [B,A,H,W,1], box [B,A,H,W,7], dir [B,A,H,W,2])."""
+    cls, box = preds["cls_preds"], preds["box_preds"]
+    pos = (torch.rand(cls.shape, device=cls.device, generator=gen) < 0.01).float()
+    p = torch.sigmoid(cls)
+    ce = F.binary_cross_entropy_with_logits(cls, pos, reduction="none")
+    mod = (pos * (1 - p) + (1 - pos) * p) ** 2.0
+    alpha = pos * 0.25 + (1 - pos) * 0.75
+    n_pos = pos.sum().clamp(min=1.0)
+    loss = (ce * mod * alpha).sum() / n_pos
+    tgt = torch.randn(box.shape, device=box.device, generator=gen)
+    loss = loss + 2.0 * (F.smooth_l1_loss(box, tgt, reduction="none") *
+                         pos.expand_as(box[..., :1])).sum() / n_pos
+    if "dir_cls_preds" in preds:
+        d = preds["dir_cls_preds"]
+        lab = (torch.rand(d.shape[:-1], device=d.device, generator=gen) < 0.5).long()
+        dl = F.cross_entropy(d.reshape(-1, d.shape[-1]), lab.reshape(-1), reduction="none")
+        loss = loss + 0.2 * (dl * pos.reshape(-1)).sum() / n_pos
+    return loss
+
+
+class TrainStep:
+    """Owns the model, the flat gradient bucket and the optimizer of ONE rank."""
+
+    def __init__(self, device, model="M2", lr=3e-4, seed=0, process_group=None):
+        self.device = device
+        self.net = randomize_(Detector(model), seed).to(device).train()
+        self.bucket = FlatGradAllReduce(self.net.parameters(), process_group)
+        self.opt = torch.optim.AdamW(self.net.parameters(), lr=lr, weight_decay=0.01)
+        self.gen = torch.Generator(device=device).manual_seed(seed)
+
+    def __call__(self, clouds):
+        """clouds: this rank's scenes (list of [N,4] cuda tensors) -> loss (device scalar)."""
+        self.bucket.zero()
+        loss = synthetic_loss(self.net(clouds), self.gen)
+        loss.backward()
+        self.bucket.reduce()
+        torch.nn.utils.clip_grad_norm_(self.net.parameters(), 10.0)  # train.py:342
+        self.opt.step()
+        return loss.detach()
