@@ -14,13 +14,23 @@ from .rpn import RPNV2
 
 
 class Detector(nn.Module):
-    def __init__(self, model="M2", max_voxels=17000):  # 17000: training cap (base.yaml:118)
+    def __init__(self, model="M2", max_voxels=17000, rpn_bf16=True):
+        # max_voxels 17000: training cap (base.yaml:118).  rpn_bf16: the dense 2-D RPN (stock
+        # torch / MIOpen, outside the hot-path scope) runs under bf16 autocast in channels_last,
+        # the MI355X analogue of the reference's apex AMP switch (train.py:217-225); the sparse
+        # front end keeps fp32 features and fp32 master weights.
         super().__init__()
         self.frontend = SparseFrontEnd(model, max_voxels=max_voxels)
         self.rpn = RPNV2(num_input_features=128)
+        self.rpn_bf16 = rpn_bf16
 
     def forward(self, clouds):
-        return self.rpn(self.frontend(clouds))
+        x = self.frontend(clouds)
+        if not (self.rpn_bf16 and x.is_cuda):
+            return self.rpn(x)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            preds = self.rpn(x.contiguous(memory_format=torch.channels_last))
+        return {k: v.float() for k, v in preds.items()}
 
 
 def synthetic_loss(preds, gen):
@@ -50,7 +60,11 @@ class TrainStep:
 
     def __init__(self, device, model="M2", lr=3e-4, seed=0, process_group=None):
         self.device = device
+        # let MIOpen time its solvers for the RPN's dense convs once per shape: its untuned
+        # heuristic picks a 13 ms weight-gradient kernel for one of them on gfx950
+        torch.backends.cudnn.benchmark = True
         self.net = randomize_(Detector(model), seed).to(device).train()
+        self.net.rpn.to(memory_format=torch.channels_last)
         self.bucket = FlatGradAllReduce(self.net.parameters(), process_group)
         self.opt = torch.optim.AdamW(self.net.parameters(), lr=lr, weight_decay=0.01)
         self.gen = torch.Generator(device=device).manual_seed(seed)

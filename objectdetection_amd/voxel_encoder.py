@@ -73,6 +73,15 @@ def _affine(norm, channels, device):
     return None, None
 
 
+def _norm_over_points(norm, x):
+    """BatchNorm1d over the channel dim of x [K,T,C].  The reference permutes to [K,C,T]
+    (voxel_encoder.py:71-73); per-channel statistics over K*T values are the same set when the
+    tensor is viewed as [K*T, C], which needs no transposed copies and takes the fast 2-D
+    batch-norm kernels (the permuted form costs 1.7 ms per layer backward on MI355X)."""
+    k, t, c = x.shape
+    return norm(x.reshape(k * t, c)).view(k, t, c)
+
+
 def _fast_path(module, *tensors):
     return (not module.training and not torch.is_grad_enabled()
             and all(t.is_cuda and t.dtype == torch.float32 for t in tensors))
@@ -91,7 +100,7 @@ class VFELayer(nn.Module):
         # reference semantics (voxel_encoder.py:65-80); the unmasked output
         voxel_count = inputs.shape[1]
         x = self.linear(inputs)
-        x = self.norm(x.permute(0, 2, 1).contiguous()).permute(0, 2, 1).contiguous()
+        x = _norm_over_points(self.norm, x)
         pointwise = F.relu(x)
         aggregated = torch.max(pointwise, dim=1, keepdim=True)[0]
         repeated = aggregated.repeat(1, voxel_count, 1)
@@ -161,7 +170,7 @@ class _VFEBase(nn.Module):
             x = vfe(x)
             x = x * mask
         x = self.linear(x)
-        x = self.norm(x.permute(0, 2, 1).contiguous()).permute(0, 2, 1).contiguous()
+        x = _norm_over_points(self.norm, x)
         x = F.relu(x)
         x = x * mask
         return torch.max(x, dim=1)[0]

@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Steady-state training steps for rocprofv3 (python tools/prof_train.py [steps])."""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from objectdetection_amd import synth  # noqa: E402
+from objectdetection_amd.train import TrainStep  # noqa: E402
+
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+dev = torch.device("cuda:0")
+step = TrainStep(dev, "M2")
+frames = [torch.from_numpy(synth.vkitti_frame(1000 + i, 20000)).to(dev) for i in range(16)]
+for i in range(3):
+    step(frames[:8])
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for i in range(steps):
+    step(frames[8 * (i % 2):8 * (i % 2) + 8])
+torch.cuda.synchronize()
+print("ms/step", (time.perf_counter() - t0) / steps * 1e3)
+
+# wall-clock breakdown of one step (synchronised between sections)
+def sect(fn):
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    r = fn()
+    torch.cuda.synchronize()
+    return r, (time.perf_counter() - t) * 1e3
+
+
+from objectdetection_amd.train import synthetic_loss  # noqa: E402
+net = step.net
+acc = {}
+for it in range(4):
+    clouds = frames[:8]
+    step.bucket.zero()
+    (v, n, c), t_vox = sect(lambda: net.frontend.voxelize(clouds))
+    f, t_vfe = sect(lambda: net.frontend.voxel_feature_extractor(v, n, c))
+    x, t_mid = sect(lambda: net.frontend.middle_feature_extractor(f, c, len(clouds)))
+
+    def rpn():
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            p = net.rpn(x.contiguous(memory_format=torch.channels_last))
+        return synthetic_loss({k: q.float() for k, q in p.items()}, step.gen)
+    loss, t_rpn = sect(rpn)
+    _, t_bwd = sect(lambda: loss.backward())
+    _, t_opt = sect(lambda: (torch.nn.utils.clip_grad_norm_(net.parameters(), 10.0), step.opt.step()))
+    acc = dict(voxelize=t_vox, vfe=t_vfe, middle_fwd=t_mid, rpn_fwd_loss=t_rpn, backward=t_bwd,
+               clip_opt=t_opt)
+print({k: round(v, 2) for k, v in acc.items()}, "sum", round(sum(acc.values()), 2))
+
+if os.environ.get("LCF_TORCH_PROF"):
+    from torch.profiler import ProfilerActivity, profile
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+        for i in range(3):
+            step(frames[:8])
+        torch.cuda.synchronize()
+    print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=35, max_name_column_width=60))
