@@ -691,20 +691,19 @@ static int cv_launch_tc(const float *feat, const float *wimg, const int *nbr, in
 
 // -------------------------------------------------------------------------- wgrad
 // dw[o][ci][co] += sum_j feat[j][ci] * dout[in_nbr[j][o]][co]
-// Workgroup = (kernel offset o, chunk of WG_ROWS input rows); each of its 4 waves walks a quarter
+// Workgroup = (kernel offset o, chunk of wg_rows input rows); each of its 4 waves walks a quarter
 // of the chunk 64 rows at a time: the rows that have a pair at offset o are COMPACTED inside the
 // wave (ballot + ds_permute: no LDS round trip), so the MFMAs (K dimension = pairs, 4 per
 // instruction) run over existing pairs only -- 2x fewer than rows on the submanifold layers,
 // 7x fewer on the strided ones.  Operands of the next 4 pairs are loaded before the MFMAs of the
 // current 4.  The four partial dW[o] are summed in LDS and added to HBM once per workgroup
 // (fp32 atomics: the sum order across workgroups is not reproducible in the last bits).
-#define WG_ROWS 1024
 
 template <int CIN, int COUT>
 __global__ void __launch_bounds__(256)
 cv_wgrad_kernel(const float *__restrict__ feat, const float *__restrict__ dout,
                 const int *__restrict__ in_nbr, int k_in, int kvol, int cin, int cout,
-                float *__restrict__ dw)
+                int wg_rows, float *__restrict__ dw)
 {
     constexpr int MT = CIN / 16;  // row tiles of dW (ci)
     constexpr int NT = COUT / 16; // col tiles of dW (co)
@@ -716,7 +715,7 @@ cv_wgrad_kernel(const float *__restrict__ feat, const float *__restrict__ dout,
     const int wave = tid >> 6;
     const int r16 = lane & 15;
     const int q = lane >> 4;
-    const int wbeg = blockIdx.x * WG_ROWS + wave * (WG_ROWS / 4);
+    const int wbeg = blockIdx.x * wg_rows + wave * (wg_rows / 4);
 
     for (int e = tid; e < CIN * COUT; e += 256) red[e] = 0.f;
     if (tid == 0) any_s = 0;
@@ -729,24 +728,60 @@ cv_wgrad_kernel(const float *__restrict__ feat, const float *__restrict__ dout,
         for (int n = 0; n < NT; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
     bool any_total = false;
 
+    // Operand fetch for pairs 4i..4i+3: lane quarter q takes pair 4i+q and reads MT (NT)
+    // CONSECUTIVE channels of its rows -- one 16-byte load per operand at 64 channels, the 16
+    // lanes of a quarter covering the whole row.  dW tile (m, n) therefore holds
+    // ci = MT*row + m, co = NT*col + n (un-permuted when written out).
+    const bool vec_ok = (cin == CIN) && (cout == COUT);
     auto fetch = [&](int cj, int cn, int c, int i, float *a, float *b) {
         const int s = 4 * i + q;
         const int j = __shfl(cj, s, 64);
         const int n = __shfl(cn, s, 64);
         const bool ok = s < c;
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            const int ci = m * 16 + r16;
-            a[m] = (ok && ci < cin) ? feat[(size_t)j * cin + ci] : 0.f;
-        }
+        for (int m = 0; m < MT; ++m) a[m] = 0.f;
 #pragma unroll
-        for (int nn = 0; nn < NT; ++nn) {
-            const int co = nn * 16 + r16;
-            b[nn] = (ok && co < cout) ? dout[(size_t)n * cout + co] : 0.f;
+        for (int nn = 0; nn < NT; ++nn) b[nn] = 0.f;
+        if (ok) {
+            const float *fa = feat + (size_t)j * cin + MT * r16;
+            const float *fb = dout + (size_t)n * cout + NT * r16;
+            if (vec_ok) {
+                if constexpr (MT % 4 == 0) {
+#pragma unroll
+                    for (int m = 0; m < MT; m += 4) {
+                        float4 x = *reinterpret_cast<const float4 *>(fa + m);
+                        a[m] = x.x; a[m + 1] = x.y; a[m + 2] = x.z; a[m + 3] = x.w;
+                    }
+                } else if constexpr (MT == 2) {
+                    float2 x = *reinterpret_cast<const float2 *>(fa);
+                    a[0] = x.x; a[1] = x.y;
+                } else {
+                    a[0] = fa[0];
+                }
+                if constexpr (NT % 4 == 0) {
+#pragma unroll
+                    for (int nn = 0; nn < NT; nn += 4) {
+                        float4 x = *reinterpret_cast<const float4 *>(fb + nn);
+                        b[nn] = x.x; b[nn + 1] = x.y; b[nn + 2] = x.z; b[nn + 3] = x.w;
+                    }
+                } else if constexpr (NT == 2) {
+                    float2 x = *reinterpret_cast<const float2 *>(fb);
+                    b[0] = x.x; b[1] = x.y;
+                } else {
+                    b[0] = fb[0];
+                }
+            } else {
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+                    if (MT * r16 + m < cin) a[m] = fa[m];
+#pragma unroll
+                for (int nn = 0; nn < NT; ++nn)
+                    if (NT * r16 + nn < cout) b[nn] = fb[nn];
+            }
         }
     };
 
-    for (int blk = 0; blk < WG_ROWS / 4 / 64; ++blk) {
+    for (int blk = 0; blk < wg_rows / 4 / 64; ++blk) {
         const int row = wbeg + blk * 64 + lane;
         const int nb = row < k_in ? in_nbr[(size_t)row * kvol + o] : -1;
         const unsigned long long m = __ballot(nb >= 0);
@@ -759,36 +794,40 @@ cv_wgrad_kernel(const float *__restrict__ feat, const float *__restrict__ dout,
         const int cj = __builtin_amdgcn_ds_permute(slot * 4, row);
         const int cn = __builtin_amdgcn_ds_permute(slot * 4, nb);
         const int steps = (c + 3) >> 2;
-        float a0[MT], b0[NT], a1[MT], b1[NT];
-        fetch(cj, cn, c, 0, a0, b0);
-        for (int i = 0; i < steps; i += 2) {
-            fetch(cj, cn, c, i + 1, a1, b1); // past the end: all lanes masked off (zeros)
+        // operands of the next 3 steps are in flight while one step's MFMAs issue
+        float a[4][MT], b[4][NT];
+        fetch(cj, cn, c, 0, a[0], b[0]);
+        fetch(cj, cn, c, 1, a[1], b[1]);
+        fetch(cj, cn, c, 2, a[2], b[2]);
+        for (int i = 0; i < steps; i += 4) {
 #pragma unroll
-            for (int mm = 0; mm < MT; ++mm)
+            for (int u = 0; u < 4; ++u) {
+                fetch(cj, cn, c, i + u + 3, a[(u + 3) & 3], b[(u + 3) & 3]); // past the end: masked
+                if (i + u < steps) {
 #pragma unroll
-                for (int nn = 0; nn < NT; ++nn)
-                    acc[mm][nn] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[mm], b0[nn], acc[mm][nn],
-                                                                       0, 0, 0);
-            fetch(cj, cn, c, i + 2, a0, b0);
+                    for (int mm = 0; mm < MT; ++mm)
 #pragma unroll
-            for (int mm = 0; mm < MT; ++mm)
-#pragma unroll
-                for (int nn = 0; nn < NT; ++nn)
-                    acc[mm][nn] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[mm], b1[nn], acc[mm][nn],
-                                                                       0, 0, 0);
+                        for (int nn = 0; nn < NT; ++nn)
+                            acc[mm][nn] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                                a[u][mm], b[u][nn], acc[mm][nn], 0, 0, 0);
+                }
+            }
         }
     }
-    if (any_total) {
-        any_s = 1;
+    // sum the four waves' partial dW[o] in LDS, one wave after the other (plain RMW)
+    if (any_total) any_s = 1;
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w && any_total) {
 #pragma unroll
-        for (int mm = 0; mm < MT; ++mm)
+            for (int mm = 0; mm < MT; ++mm)
 #pragma unroll
-            for (int nn = 0; nn < NT; ++nn)
+                for (int nn = 0; nn < NT; ++nn)
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    atomicAdd(&red[(mm * 16 + q * 4 + r) * COUT + nn * 16 + r16], acc[mm][nn][r]);
+                    for (int r = 0; r < 4; ++r)
+                        red[(MT * (q * 4 + r) + mm) * COUT + NT * r16 + nn] += acc[mm][nn][r];
+        }
+        __syncthreads();
     }
-    __syncthreads();
     if (!any_s) return;
     float *dwo = dw + (size_t)o * cin * cout;
     for (int e = tid; e < CIN * COUT; e += 256) {
@@ -957,9 +996,15 @@ template <int CIN, int COUT>
 static int cv_launch_wgrad(const float *feat, const float *dout, const int *in_nbr, int k_in,
                            int kvol, int cin, int cout, float *dw, hipStream_t st)
 {
-    dim3 grid((k_in + WG_ROWS - 1) / WG_ROWS, kvol);
-    cv_wgrad_kernel<(CIN < 16 ? 16 : CIN), COUT><<<grid, 256, 0, st>>>(feat, dout, in_nbr, k_in,
-                                                                        kvol, cin, cout, dw);
+    // rows per workgroup (multiple of 256): ~3000 workgroups per launch, so that the per-
+    // workgroup reduction and its atomics stay small next to the MFMA work
+    long long want = ((long long)k_in * kvol + 2999) / 3000;
+    int wg_rows = (int)((want + 255) / 256 * 256);
+    if (wg_rows < 256) wg_rows = 256;
+    if (wg_rows > 16384) wg_rows = 16384;
+    dim3 grid((k_in + wg_rows - 1) / wg_rows, kvol);
+    cv_wgrad_kernel<(CIN < 16 ? 16 : CIN), COUT><<<grid, 256, 0, st>>>(
+        feat, dout, in_nbr, k_in, kvol, cin, cout, wg_rows, dw);
     LCF_CHECK_LAUNCH();
     return LCF_OK;
 }
