@@ -152,12 +152,17 @@ int lcf_indice_conv_fwd(const float *feat, const float *wimg, const int *nbr, in
 int lcf_indice_conv_wgrad(const float *feat, const float *dout, const int *in_nbr, int k_in,
                           int kvol, int cin, int cout, float *dw, void *stream);
 
+/* Fill `bytes` (multiple of 4, 4-byte aligned) with a 32-bit pattern: a plain kernel, usable
+ * where hipMemsetAsync is not wanted (graph capture; no counterpart in the reference). */
+int lcf_fill_u32(void *p, uint32_t value, size_t bytes, void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * SparseConvTensor.dense() (second/pytorch/models/middle.py:206): out [B,C,D,H,W] f32 is
- * zero-filled and scattered from feat [k,c], coors [k,4].  dense_bwd gathers it back.
+ * zero-filled (zero_fill != 0; a caller that has already cleared `out`, e.g. on another stream,
+ * passes 0) and scattered from feat [k,c], coors [k,4].  dense_bwd gathers it back.
  */
 int lcf_dense(const float *feat, const int *coors, int k, const int *k_dev, int c, int batch,
-              const int shape[3], float *out, void *stream);
+              const int shape[3], int zero_fill, float *out, void *stream);
 int lcf_dense_bwd(const float *dout, const int *coors, int k, int c, int batch,
                   const int shape[3], float *dfeat, void *stream);
 

@@ -47,8 +47,8 @@ SYMBOLS = {
                                     c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "lcf_indice_conv_wgrad": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                       c_void_p, c_void_p]),
-    "lcf_dense": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, _PI3, c_void_p,
-                          c_void_p]),
+    "lcf_dense": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, _PI3, c_int,
+                          c_void_p, c_void_p]),
     "lcf_dense_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, _PI3, c_void_p,
                               c_void_p]),
     "lcf_vfe_mean": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p,
@@ -57,6 +57,7 @@ SYMBOLS = {
                                 c_void_p]),
     "lcf_vfe_pool": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p,
                              c_void_p, c_int, c_void_p, c_void_p]),
+    "lcf_fill_u32": (c_int, [c_void_p, ctypes.c_uint32, c_size_t, c_void_p]),
     "lcf_vfe_fused": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int,
                               c_int] + [c_void_p] * 11),
 }

@@ -45,6 +45,12 @@ int lcf_fill32(void *p, uint32_t v, size_t bytes, hipStream_t st)
     return LCF_OK;
 }
 
+extern "C" int lcf_fill_u32(void *p, uint32_t value, size_t bytes, void *stream)
+{
+    if (!p && bytes) return LCF_ERR_ARG;
+    return lcf_fill32(p, value, bytes, (hipStream_t)stream);
+}
+
 // ---------------------------------------------------------------- dense
 // SparseConvTensor.dense() (second/pytorch/models/middle.py:206): [B,C,D,H,W] contiguous.
 // Thread = (row, channel); a row's C values land C*svol*4 bytes apart, so writes are scattered by
@@ -86,13 +92,13 @@ dense_gather_kernel(const float *__restrict__ dout, const int *__restrict__ coor
 }
 
 extern "C" int lcf_dense(const float *feat, const int *coors, int k, const int *k_dev, int c,
-                         int batch, const int shape[3], float *out, void *stream)
+                         int batch, const int shape[3], int zero_fill, float *out, void *stream)
 {
     if (k < 0 || c <= 0 || batch <= 0 || !shape || !out || (k > 0 && (!feat || !coors)))
         return LCF_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     size_t bytes = (size_t)batch * c * shape[0] * shape[1] * shape[2] * 4;
-    if (lcf_fill32(out, 0u, bytes, st) != LCF_OK) return LCF_ERR_LAUNCH;
+    if (zero_fill && lcf_fill32(out, 0u, bytes, st) != LCF_OK) return LCF_ERR_LAUNCH;
     if (k == 0) return LCF_OK;
     long long total = (long long)k * c;
     dense_scatter_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(

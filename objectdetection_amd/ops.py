@@ -294,7 +294,7 @@ class DenseFunction(torch.autograd.Function):
         k, c = x.shape
         out = torch.empty((batch_size, c, *shape), dtype=torch.float32, device=x.device)
         check(_lib.lib().lcf_dense(_ptr(x), _ptr(indices), k, None, c, int(batch_size),
-                                   i3(shape), _ptr(out), _stream()))
+                                   i3(shape), 1, _ptr(out), _stream()))
         ctx.save_for_backward(indices)
         ctx.meta = (k, c, int(batch_size), list(shape), features.dtype)
         return out.to(features.dtype)
