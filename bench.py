@@ -142,6 +142,8 @@ def main():
     ap.add_argument("--train-steps", type=int, default=10,
                     help="timed training steps of the second measurement (0 = skip it)")
     ap.add_argument("--train-batch", type=int, default=8, help="frames per rank per step")
+    ap.add_argument("--inflight", type=int, default=1,
+                    help="independent frames in flight (one FrameEngine + stream each)")
     ap.add_argument("--eager", action="store_true",
                     help="module-by-module path (spconv API, host syncs) instead of the "
                          "graph-captured FrameEngine")
@@ -175,6 +177,18 @@ def main():
             # one hipGraph replay per frame; capacities calibrated on this rank's frames
             engine = model.engine(calib=clouds)
             step = engine.forward
+            if args.inflight > 1:
+                # serving with several batch-1 requests in flight: one engine (own buffers, own
+                # graph) per slot, each on its own stream; frames alternate over the slots
+                streams = [torch.cuda.Stream(device=dev) for _ in range(args.inflight)]
+                engines = [engine] + [model.engine(calib=clouds) for _ in range(args.inflight - 1)]
+                slot = [0]
+
+                def step(c):
+                    i = slot[0] % args.inflight
+                    slot[0] += 1
+                    with torch.cuda.stream(streams[i]):
+                        return engines[i].forward(c)
         for i in range(args.warmup):
             out = step(clouds[i % len(clouds)])
         barrier()
@@ -183,6 +197,10 @@ def main():
             out = step(clouds[i % len(clouds)])
         barrier()
         elapsed = time.perf_counter() - t0
+        if not args.eager and args.inflight > 1:
+            for e in engines:
+                e.check()
+            out = engines[(args.steps - 1) % args.inflight].out
         if not args.eager:
             engine.check()  # no frame may have exceeded a level capacity
             ref = model([clouds[(args.steps - 1) % len(clouds)]])
@@ -213,6 +231,7 @@ def main():
                                    "(BASELINE.json configs[1])",
                        "model": args.model, "points_per_frame": args.points,
                        "path": "eager modules" if args.eager else "FrameEngine (hipGraph replay)",
+                       "frames_in_flight": 1 if args.eager else args.inflight,
                        "parallelism": f"replicas x{world} (scene-sharded, no collective)"},
         }
         if roof is not None:
