@@ -124,7 +124,8 @@ def train_measurement(args, dev, rank, world, dist, barrier):
             "value": round(world * b * args.train_steps / el, 2), "unit": "frames/s",
             "ms_per_step": round(el / args.train_steps * 1e3, 2), "steps": args.train_steps,
             "global_batch": world * b, "scaling": "weak",
-            "dtype": "f32 sparse front end (fp32 MFMA), bf16 autocast RPN",
+            "dtype": "bf16 MFMA indice_conv fwd/dgrad (fp32 accumulate, fp32 wgrad and master "
+                     "weights), bf16 autocast RPN",
             "allreduce_bytes": 4 * nparams if world > 1 else 0,
             "loss": round(float(loss), 4)}
 

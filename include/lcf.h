@@ -149,6 +149,18 @@ int lcf_weight_image(const float *w, int kvol, int cin, int cout, int transpose,
 int lcf_indice_conv_fwd(const float *feat, const float *wimg, const int *nbr, int k_out,
                         const int *k_out_dev, int kvol, int cin, int cout, const float *scale,
                         const float *shift, int relu, float *out, void *stream);
+/* bf16-operand variant (BASELINE.json configs[2]: "bf16 MFMA indice_conv" for training): the
+ * features stay fp32 in HBM and are rounded to bf16 when they enter LDS, the weights come as a
+ * bf16 image (lcf_weight_image_bf16: kvol*cin*cout 2-byte elements in
+ * v_mfma_f32_16x16x32_bf16 fragment order), accumulation and output are fp32.  cin and cout must
+ * be 32, 64 or 128 (LCF_ERR_UNSUPPORTED otherwise: the caller keeps the fp32 entry point).
+ * Stated tolerance vs the fp32 oracle: 2e-2 of the output's max magnitude (tests). */
+int lcf_weight_image_bf16(const float *w, int kvol, int cin, int cout, int transpose, void *img,
+                          void *stream);
+int lcf_indice_conv_fwd_bf16(const float *feat, const void *wimg_bf16, const int *nbr, int k_out,
+                             const int *k_out_dev, int kvol, int cin, int cout,
+                             const float *scale, const float *shift, int relu, float *out,
+                             void *stream);
 int lcf_indice_conv_wgrad(const float *feat, const float *dout, const int *in_nbr, int k_in,
                           int kvol, int cin, int cout, float *dw, void *stream);
 

@@ -45,6 +45,10 @@ SYMBOLS = {
     "lcf_weight_image": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "lcf_indice_conv_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int,
                                     c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "lcf_weight_image_bf16": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "lcf_indice_conv_fwd_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int,
+                                         c_int, c_int, c_void_p, c_void_p, c_int, c_void_p,
+                                         c_void_p]),
     "lcf_indice_conv_wgrad": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                       c_void_p, c_void_p]),
     "lcf_dense": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, _PI3, c_int,

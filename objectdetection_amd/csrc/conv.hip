@@ -16,6 +16,8 @@
 #include "common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 #define CV_ROWS_PER_WAVE 16
 #define CV_WAVES 4
@@ -339,9 +341,10 @@ struct TcCfg {
 
 static size_t tc_max(size_t a, size_t b) { return a > b ? a : b; }
 
-static size_t tc_lds_bytes(int CIN, int COUT, int TR, int kvol)
+static size_t tc_lds_bytes(int CIN, int COUT, int TR, int kvol, bool bf16 = false)
 {
-    size_t b = (size_t)2 * TR * (CIN + 4) * 4;                            // A rows of one offset
+    size_t b = bf16 ? (size_t)2 * TR * (CIN + 8) * 2                      // A rows, bf16
+                    : (size_t)2 * TR * (CIN + 4) * 4;                     // A rows of one offset
     b += tc_max((size_t)(TR + 1) * (COUT + 4) * 4, (size_t)TR * kvol * 4); // tile | nbr tile
     b = (b + 15) & ~(size_t)15;
     b += (size_t)(TR + 16) * kvol * 4;                                    // item entries
@@ -351,7 +354,10 @@ static size_t tc_lds_bytes(int CIN, int COUT, int TR, int kvol)
 
 #define TC_THREADS(COUT) (((COUT) / 16 >= 4 ? 4 : (COUT) / 16) * 64)
 
-template <int CIN, int COUT, int TR, bool EXACT>
+// BF16: operands rounded to bf16 (features when they enter LDS, weights in a bf16 image in
+// v_mfma_f32_16x16x32_bf16 fragment order), fp32 accumulation and fp32 output: the training
+// variant BASELINE.json configs[2] names.  Needs Cin a multiple of 32.
+template <int CIN, int COUT, int TR, bool EXACT, bool BF16>
 __global__ void __launch_bounds__(TC_THREADS(COUT))
 cv_tc_kernel(const float *__restrict__ feat, const float *__restrict__ wimg,
              const int *__restrict__ nbr, int k_cap, const int *__restrict__ k_dev, int kvol,
@@ -370,11 +376,15 @@ cv_tc_kernel(const float *__restrict__ feat, const float *__restrict__ wimg,
     if (row0 >= k_out) return;
 
     extern __shared__ __align__(16) unsigned char smem[];
-    float *al = reinterpret_cast<float *>(smem);                 // [2][TR][ASTR]
-    float *ot = al + 2 * TR * ASTR;                              // [TR + dump row][OSTR]
+    constexpr int ASTRH = CIN + 8;                               // bf16 A row stride (halfs)
+    constexpr int KS = CIN >= 32 ? CIN / 32 : 1;                 // bf16 k-steps of 32
+    constexpr size_t ABYTES = BF16 ? (size_t)2 * TR * ASTRH * 2 : (size_t)2 * TR * ASTR * 4;
+    float *al = reinterpret_cast<float *>(smem);                 // [2][TR][ASTR]  (fp32 form)
+    __bf16 *alh = reinterpret_cast<__bf16 *>(smem);              // [2][TR][ASTRH] (bf16 form)
+    float *ot = reinterpret_cast<float *>(smem + ABYTES);        // [TR + dump row][OSTR]
     int *nl = reinterpret_cast<int *>(ot);                       // [TR][kvol], dead before ot lives
     size_t otb = (size_t)(TR + 1) * OSTR * 4, nlb = (size_t)TR * kvol * 4;
-    size_t off = (size_t)2 * TR * ASTR * 4 + (otb > nlb ? otb : nlb);
+    size_t off = ABYTES + (otb > nlb ? otb : nlb);
     off = (off + 15) & ~(size_t)15;
     unsigned *ent = reinterpret_cast<unsigned *>(smem + off);    // [items][16] entries
     int *cnt = reinterpret_cast<int *>(ent + (TR + 16) * kvol);  // [64] rows per offset
@@ -448,7 +458,10 @@ cv_tc_kernel(const float *__restrict__ feat, const float *__restrict__ wimg,
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
 
     struct AReg { float4 v[MAXG][APT]; };
-    struct BReg { float b[NT][KL]; };
+    struct BReg {
+        float b[NT][BF16 ? 1 : KL];
+        bf16x8 h[NT][BF16 ? KS : 1];
+    };
 
     // rows of the ng groups starting at item i0: thread -> (row r of a group, 16-byte chunk cc)
     auto agather = [&](int i0, int ng) -> AReg {
@@ -480,6 +493,7 @@ cv_tc_kernel(const float *__restrict__ feat, const float *__restrict__ wimg,
     };
     auto astore = [&](int buf, const AReg &a, int ng) {
         float *dst = al + buf * TR * ASTR;
+        __bf16 *dsth = alh + buf * TR * ASTRH;
 #pragma unroll
         for (int g = 0; g < MAXG; ++g) {
 #pragma unroll
@@ -487,7 +501,14 @@ cv_tc_kernel(const float *__restrict__ feat, const float *__restrict__ wimg,
                 const int ch = tid + x * THREADS;
                 if (g < ng && (AFULL || ch < ACH)) {
                     const int r = ch / CH, cc = ch % CH;
-                    *reinterpret_cast<float4 *>(dst + (g * 16 + r) * ASTR + cc * 4) = a.v[g][x];
+                    if constexpr (BF16) {
+                        const float4 v = a.v[g][x];
+                        bf16x4 h = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+                        *reinterpret_cast<bf16x4 *>(dsth + (g * 16 + r) * ASTRH + cc * 4) = h;
+                    } else {
+                        *reinterpret_cast<float4 *>(dst + (g * 16 + r) * ASTR + cc * 4) =
+                            a.v[g][x];
+                    }
                 }
             }
         }
@@ -495,6 +516,19 @@ cv_tc_kernel(const float *__restrict__ feat, const float *__restrict__ wimg,
     // this wave's column slice of W[o], in fragment order, straight from the image (L2)
     auto bload = [&](int o) -> BReg {
         BReg w;
+        if constexpr (BF16) {
+            // image [o][tg][ks][q][r16][8]: lane (q, r16) holds B[k = 32ks + 8q + j][col]
+            const __bf16 *wo = reinterpret_cast<const __bf16 *>(wimg) + (size_t)o * WELEMS;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int tg = wave * NT + t;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks)
+                    w.h[t][ks] = *reinterpret_cast<const bf16x8 *>(
+                        wo + (((tg * KS + ks) * 4 + q) * 16 + r16) * 8);
+            }
+            return w;
+        }
         const float *wo = wimg + (size_t)o * WELEMS;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
@@ -523,7 +557,14 @@ cv_tc_kernel(const float *__restrict__ feat, const float *__restrict__ wimg,
     auto compute = [&](int abuf, int g, const BReg &w, int i) {
         const float *ap = al + (abuf * TR + g * 16 + r16) * ASTR + q * KL;
         float a[KL];
-        if constexpr (KL >= 4) {
+        bf16x8 ah[KS];
+        if constexpr (BF16) {
+            // lane (r16, q) holds A[row r16][k = 32ks + 8q + j]
+            const __bf16 *aph = alh + (abuf * TR + g * 16 + r16) * ASTRH + q * 8;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+                ah[ks] = *reinterpret_cast<const bf16x8 *>(aph + ks * 32);
+        } else if constexpr (KL >= 4) {
 #pragma unroll
             for (int j = 0; j < KL / 4; ++j) {
                 float4 x = reinterpret_cast<const float4 *>(ap)[j];
@@ -549,12 +590,21 @@ cv_tc_kernel(const float *__restrict__ feat, const float *__restrict__ wimg,
             acc[t][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
             acc[t][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
+        if constexpr (BF16) {
 #pragma unroll
-        for (int s = 0; s < KL; ++s)
+            for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-            for (int t = 0; t < NT; ++t)
-                acc[t][s & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], w.b[t][s],
-                                                                     acc[t][s & 1], 0, 0, 0);
+                for (int t = 0; t < NT; ++t)
+                    acc[t][ks & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                        ah[ks], w.h[t][ks], acc[t][ks & 1], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int s = 0; s < KL; ++s)
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    acc[t][s & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], w.b[t][s],
+                                                                         acc[t][s & 1], 0, 0, 0);
+        }
         // tile[orow][cols of this wave] += group result (col = lane&15); exclusive ownership
         float cur[4][NT];
 #pragma unroll
@@ -643,31 +693,38 @@ cv_tc_kernel(const float *__restrict__ feat, const float *__restrict__ wimg,
 
 static int g_tc_rows = 0; // LCF_OPT_CONV_TILE: 0 = choose from the row count, 32 or 64
 
-template <int CIN, int COUT, int TR>
+template <int CIN, int COUT, int TR, bool BF16 = false>
 static int cv_launch_tc_n(const float *feat, const float *wimg, const int *nbr, int k_cap,
                           const int *k_dev, int kvol, int cin, int cout, const float *scale,
                           const float *shift, int relu, float *out, hipStream_t st)
 {
     using C = TcCfg<CIN, COUT, TR>;
-    size_t lds = tc_lds_bytes(CIN, COUT, TR, kvol);
+    size_t lds = tc_lds_bytes(CIN, COUT, TR, kvol, BF16);
     if (lds > 160 * 1024) return LCF_ERR_UNSUPPORTED;
     static size_t lds_set = 0; // per instantiation: largest dynamic LDS size opted into so far
     if (lds > 64 * 1024 && lds > lds_set) {
-        if (hipFuncSetAttribute((const void *)cv_tc_kernel<CIN, COUT, TR, true>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds) != hipSuccess ||
-            hipFuncSetAttribute((const void *)cv_tc_kernel<CIN, COUT, TR, false>,
+        if (hipFuncSetAttribute((const void *)cv_tc_kernel<CIN, COUT, TR, true, BF16>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds) != hipSuccess)
             return LCF_ERR_LAUNCH;
+        if constexpr (!BF16) {
+            if (hipFuncSetAttribute((const void *)cv_tc_kernel<CIN, COUT, TR, false, false>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lds) != hipSuccess)
+                return LCF_ERR_LAUNCH;
+        }
         lds_set = lds;
     }
     int nb = (k_cap + TR - 1) / TR;
-    if (cin == CIN)
-        cv_tc_kernel<CIN, COUT, TR, true><<<nb, C::THREADS, lds, st>>>(
+    if constexpr (BF16) {
+        if (cin != CIN) return LCF_ERR_UNSUPPORTED;
+        cv_tc_kernel<CIN, COUT, TR, true, true><<<nb, C::THREADS, lds, st>>>(
+            feat, wimg, nbr, k_cap, k_dev, kvol, cin, cout, scale, shift, relu, out);
+    } else if (cin == CIN)
+        cv_tc_kernel<CIN, COUT, TR, true, false><<<nb, C::THREADS, lds, st>>>(
             feat, wimg, nbr, k_cap, k_dev, kvol, cin, cout, scale, shift, relu, out);
     else
-        cv_tc_kernel<CIN, COUT, TR, false><<<nb, C::THREADS, lds, st>>>(
+        cv_tc_kernel<CIN, COUT, TR, false, false><<<nb, C::THREADS, lds, st>>>(
             feat, wimg, nbr, k_cap, k_dev, kvol, cin, cout, scale, shift, relu, out);
     LCF_CHECK_LAUNCH();
     return LCF_OK;
@@ -687,6 +744,84 @@ static int cv_launch_tc(const float *feat, const float *wimg, const int *nbr, in
                                              scale, shift, relu, out, st);
     return cv_launch_tc_n<CIN, COUT, 32>(feat, wimg, nbr, k_cap, k_dev, kvol, cin, cout, scale,
                                          shift, relu, out, st);
+}
+
+// -------------------------------------------------------------------------- bf16 entry points
+__global__ void __launch_bounds__(256)
+cv_weight_image_bf16_kernel(const float *__restrict__ w, int kvol, int cin, int cout, int CIN,
+                            int COUT, int transpose, __bf16 *__restrict__ img)
+{
+    // image [o][tg][ks][q][r16][j] <- W'[k = 32ks + 8q + j][c = 16tg + r16], W' = W[o] or W[o]^T
+    const int KS = CIN / 32;
+    long long total = (long long)kvol * CIN * COUT;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+         e += (long long)gridDim.x * blockDim.x) {
+        int o = (int)(e / (CIN * COUT));
+        int r = (int)(e - (long long)o * CIN * COUT);
+        int j = r & 7, r16 = (r >> 3) & 15, q = (r >> 7) & 3;
+        int ks = (r >> 9) % KS, tg = (r >> 9) / KS;
+        int k = 32 * ks + 8 * q + j, c = 16 * tg + r16;
+        float v = 0.f;
+        if (!transpose) {
+            if (k < cin && c < cout) v = w[((size_t)o * cin + k) * cout + c];
+        } else {
+            if (k < cout && c < cin) v = w[((size_t)o * cin + c) * cout + k];
+        }
+        img[e] = (__bf16)v;
+    }
+}
+
+static bool cv_bf16_ok(int c) { return c == 32 || c == 64 || c == 128; }
+
+extern "C" int lcf_weight_image_bf16(const float *w, int kvol, int cin, int cout, int transpose,
+                                     void *img, void *stream)
+{
+    if (!w || !img || kvol <= 0 || cin <= 0 || cout <= 0) return LCF_ERR_ARG;
+    if (!cv_bf16_ok(cin) || !cv_bf16_ok(cout)) return LCF_ERR_UNSUPPORTED;
+    int CIN = transpose ? cout : cin, COUT = transpose ? cin : cout;
+    long long total = (long long)kvol * CIN * COUT;
+    int nb = (int)((total + 255) / 256);
+    if (nb > 2048) nb = 2048;
+    cv_weight_image_bf16_kernel<<<nb, 256, 0, (hipStream_t)stream>>>(
+        w, kvol, cin, cout, CIN, COUT, transpose, (__bf16 *)img);
+    LCF_CHECK_LAUNCH();
+    return LCF_OK;
+}
+
+template <int CIN, int COUT>
+static int cv_launch_tc_bf16(const float *feat, const float *wimg, const int *nbr, int k_cap,
+                             const int *k_dev, int kvol, int cin, int cout, const float *scale,
+                             const float *shift, int relu, float *out, hipStream_t st)
+{
+    return cv_launch_tc_n<CIN, COUT, 32, true>(feat, wimg, nbr, k_cap, k_dev, kvol, cin, cout,
+                                               scale, shift, relu, out, st);
+}
+
+extern "C" int lcf_indice_conv_fwd_bf16(const float *feat, const void *wimg_bf16, const int *nbr,
+                                        int k_out, const int *k_out_dev, int kvol, int cin,
+                                        int cout, const float *scale, const float *shift,
+                                        int relu, float *out, void *stream)
+{
+    if (k_out < 0 || kvol <= 0 || !wimg_bf16 || (k_out > 0 && (!feat || !out)) ||
+        (!nbr && kvol != 1))
+        return LCF_ERR_ARG;
+    if (kvol > LCF_MAX_KVOL || !cv_bf16_ok(cin) || !cv_bf16_ok(cout)) return LCF_ERR_UNSUPPORTED;
+    if (((uintptr_t)feat & 15) || ((uintptr_t)wimg_bf16 & 15) || ((uintptr_t)out & 15) ||
+        ((uintptr_t)scale & 15) || ((uintptr_t)shift & 15))
+        return LCF_ERR_ARG;
+    if (k_out >= (1 << 25)) return LCF_ERR_RANGE;
+    if (k_out == 0) return LCF_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const float *wi = (const float *)wimg_bf16;
+#define CV_BF16_CASE(A, B)                                                                  \
+    if (cin == A && cout == B)                                                              \
+        return cv_launch_tc_bf16<A, B>(feat, wi, nbr, k_out, k_out_dev, kvol, cin, cout, scale, \
+                                       shift, relu, out, st);
+    CV_BF16_CASE(32, 32) CV_BF16_CASE(32, 64) CV_BF16_CASE(32, 128)
+    CV_BF16_CASE(64, 32) CV_BF16_CASE(64, 64) CV_BF16_CASE(64, 128)
+    CV_BF16_CASE(128, 32) CV_BF16_CASE(128, 64) CV_BF16_CASE(128, 128)
+#undef CV_BF16_CASE
+    return LCF_ERR_UNSUPPORTED;
 }
 
 // -------------------------------------------------------------------------- wgrad

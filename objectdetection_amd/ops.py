@@ -224,6 +224,62 @@ def weight_image(weight, transpose=False):
     return img
 
 
+_CONV_MATH = ["f32"]
+
+
+class conv_math:
+    """Context manager / setter for the MFMA operand type of the TRAINING indice_conv
+    (forward + dgrad through ``indice_conv``): "f32" (default, exact fp32 MFMA) or "bf16"
+    (bf16 operands, fp32 accumulate; layers whose channels are not 32/64/128 stay fp32)."""
+
+    def __init__(self, mode):
+        if mode not in ("f32", "bf16"):
+            raise ValueError("conv math mode must be 'f32' or 'bf16'")
+        self.mode, self.prev = mode, None
+
+    def __enter__(self):
+        self.prev = _CONV_MATH[0]
+        _CONV_MATH[0] = self.mode
+        return self
+
+    def __exit__(self, *exc):
+        _CONV_MATH[0] = self.prev
+
+
+def set_conv_math(mode):
+    conv_math(mode).__enter__()
+
+
+def bf16_supported(cin, cout):
+    return cin in (32, 64, 128) and cout in (32, 64, 128)
+
+
+def weight_image_bf16(weight, transpose=False):
+    """weight [...,Cin,Cout] -> bf16 MFMA weight image (int16 storage) for lcf_indice_conv_fwd_bf16."""
+    _need_cuda(weight)
+    w = weight.detach().float().contiguous()
+    cin, cout = int(w.shape[-2]), int(w.shape[-1])
+    kvol = w.numel() // (cin * cout)
+    img = torch.empty((kvol * cin * cout,), dtype=torch.int16, device=w.device)
+    check(_lib.lib().lcf_weight_image_bf16(_ptr(w), kvol, cin, cout, int(transpose), _ptr(img),
+                                           _stream()))
+    return img
+
+
+def conv_forward_bf16(features, wimg, nbr, n_rows, kvol, cin, cout, scale=None, shift=None,
+                      relu=False, n_rows_dev=None, out=None):
+    """conv_forward with bf16 MFMA operands (fp32 accumulate, fp32 in/out)."""
+    _need_cuda(features, wimg, nbr)
+    x = features.contiguous()
+    if out is None:
+        out = torch.empty((n_rows, cout), dtype=torch.float32, device=x.device)
+    check(_lib.lib().lcf_indice_conv_fwd_bf16(_ptr(x), _ptr(wimg), _ptr(nbr), int(n_rows),
+                                              _ptr(n_rows_dev), int(kvol), int(cin), int(cout),
+                                              _ptr(scale), _ptr(shift), int(bool(relu)),
+                                              _ptr(out), _stream()))
+    return out
+
+
 def conv_forward(features, wimg, nbr, n_rows, kvol, cin, cout, scale=None, shift=None,
                  relu=False, n_rows_dev=None, out=None):
     """out[n_rows,cout] = act((sum_o features[nbr[n][o]] @ W[o]) * scale + shift).
@@ -258,8 +314,13 @@ class IndiceConvFunction(torch.autograd.Function):
     def forward(ctx, features, weight, rulebook):
         cin, cout = int(weight.shape[-2]), int(weight.shape[-1])
         x = features.float() if features.dtype != torch.float32 else features
-        out = conv_forward(x, weight_image(weight), rulebook.out_nbr, rulebook.k_out,
-                           rulebook.kvol, cin, cout)
+        ctx.bf16 = _CONV_MATH[0] == "bf16" and bf16_supported(cin, cout)
+        if ctx.bf16:
+            out = conv_forward_bf16(x, weight_image_bf16(weight), rulebook.out_nbr,
+                                    rulebook.k_out, rulebook.kvol, cin, cout)
+        else:
+            out = conv_forward(x, weight_image(weight), rulebook.out_nbr, rulebook.k_out,
+                               rulebook.kvol, cin, cout)
         ctx.save_for_backward(x, weight)
         ctx.rulebook = rulebook
         ctx.in_dtype = features.dtype
@@ -272,7 +333,10 @@ class IndiceConvFunction(torch.autograd.Function):
         cin, cout = int(weight.shape[-2]), int(weight.shape[-1])
         g = grad_out.float().contiguous()
         din = dw = None
-        if ctx.needs_input_grad[0]:
+        if ctx.needs_input_grad[0] and ctx.bf16:
+            din = conv_forward_bf16(g, weight_image_bf16(weight, transpose=True), rb.in_nbr,
+                                    rb.k_in, rb.kvol, cout, cin).to(ctx.in_dtype)
+        elif ctx.needs_input_grad[0]:
             din = conv_forward(g, weight_image(weight, transpose=True), rb.in_nbr, rb.k_in,
                                rb.kvol, cout, cin).to(ctx.in_dtype)
         if ctx.needs_input_grad[1]:

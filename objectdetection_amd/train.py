@@ -58,8 +58,12 @@ def synthetic_loss(preds, gen):
 class TrainStep:
     """Owns the model, the flat gradient bucket and the optimizer of ONE rank."""
 
-    def __init__(self, device, model="M2", lr=3e-4, seed=0, process_group=None):
+    def __init__(self, device, model="M2", lr=3e-4, seed=0, process_group=None,
+                 conv_math="bf16"):
+        # conv_math "bf16": indice_conv forward + dgrad with bf16 MFMA operands and fp32
+        # accumulation (BASELINE.json configs[2]); fp32 master weights, fp32 wgrad.
         self.device = device
+        self.conv_math = conv_math
         # let MIOpen time its solvers for the RPN's dense convs once per shape: its untuned
         # heuristic picks a 13 ms weight-gradient kernel for one of them on gfx950
         torch.backends.cudnn.benchmark = True
@@ -71,9 +75,11 @@ class TrainStep:
 
     def __call__(self, clouds):
         """clouds: this rank's scenes (list of [N,4] cuda tensors) -> loss (device scalar)."""
+        from . import ops
         self.bucket.zero()
-        loss = synthetic_loss(self.net(clouds), self.gen)
-        loss.backward()
+        with ops.conv_math(self.conv_math):
+            loss = synthetic_loss(self.net(clouds), self.gen)
+            loss.backward()
         self.bucket.reduce()
         torch.nn.utils.clip_grad_norm_(self.net.parameters(), 10.0)  # train.py:342
         self.opt.step()

@@ -130,3 +130,43 @@ def test_dense_matches_oracle(oracle, cuda):
     c = torch.from_numpy(coors).long().to(cuda)
     ref_g = gout[c[:, 0], :, c[:, 1], c[:, 2], c[:, 3]]
     assert torch.equal(xt.grad, ref_g)
+
+
+BF16_RTOL = 2e-2  # stated bf16 tolerance (north star): bf16 operands, fp32 accumulation
+
+
+@pytest.mark.parametrize("cin,cout,subm", [(32, 32, True), (64, 64, True), (32, 64, False),
+                                           (64, 128, True), (128, 64, False)])
+def test_bf16_forward_and_dgrad_match_oracle(oracle, cuda, cin, cout, subm):
+    """bf16-operand MFMA variant (training) vs the fp32 oracle, within the stated tolerance, and
+    exactly equal to the fp32 kernel on inputs that bf16 represents exactly."""
+    rng = np.random.default_rng(cin + cout)
+    coors = _frame_coors(oracle, 2, 6000)
+    shape = [41, 1600, 1408]
+    k = coors.shape[0]
+    x = rng.standard_normal((k, cin)).astype(np.float32)
+    w = (rng.standard_normal((3, 3, 3, cin, cout)) / np.sqrt(27 * cin)).astype(np.float32)
+    if subm:
+        pairs, pn = oracle.rulebook_subm(coors, 1, shape, 3)
+        k_out = k
+    else:
+        oc, pairs, pn, _ = oracle.rulebook_conv(coors, 1, shape, 3, 2, 1)
+        k_out = oc.shape[0]
+    ref = oracle.indice_conv_fwd(x, w, pairs, pn, k_out)
+    rb = ops.build_rulebook(torch.from_numpy(coors).to(cuda), 1, shape, 3, 2, 1, 1, subm)
+    xt = torch.from_numpy(x).to(cuda).requires_grad_(True)
+    wt = torch.from_numpy(w).to(cuda).requires_grad_(True)
+    with ops.conv_math("bf16"):
+        out = ops.indice_conv(xt, wt, rb)
+        g = rng.standard_normal((k_out, cout)).astype(np.float32)
+        out.backward(torch.from_numpy(g).to(cuda))
+    assert rel_err(out.detach().cpu().numpy(), ref) < BF16_RTOL
+    din_ref, dw_ref = oracle.indice_conv_bwd(x, w, g, pairs, pn)
+    assert rel_err(xt.grad.cpu().numpy(), din_ref) < BF16_RTOL
+    assert rel_err(wt.grad.cpu().numpy(), dw_ref) < RTOL  # wgrad stays fp32
+    # bf16-exact inputs: products are exact in fp32, only the summation order differs
+    xe = torch.from_numpy(x).to(cuda).bfloat16().float()
+    we = torch.from_numpy(w).to(cuda).bfloat16().float()
+    a = ops.conv_forward_bf16(xe, ops.weight_image_bf16(we), rb.out_nbr, rb.k_out, 27, cin, cout)
+    b = ops.conv_forward(xe, ops.weight_image(we), rb.out_nbr, rb.k_out, 27, cin, cout)
+    assert rel_err(a.cpu().numpy(), b.cpu().numpy()) < 1e-5

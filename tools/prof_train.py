@@ -12,7 +12,7 @@ from objectdetection_amd.train import TrainStep  # noqa: E402
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 dev = torch.device("cuda:0")
-step = TrainStep(dev, "M2")
+step = TrainStep(dev, "M2", conv_math=os.environ.get("LCF_CONV_MATH", "bf16"))
 frames = [torch.from_numpy(synth.vkitti_frame(1000 + i, 20000)).to(dev) for i in range(16)]
 for i in range(3):
     step(frames[:8])
