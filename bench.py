@@ -84,9 +84,9 @@ def dominant_kernel_roofline(model, cloud, reps=20):
             "flops_per_launch": round(total_flops / n, 0)}
 
 
-def cpu_baseline(model_name, cloud_np, budget_s):
+def cpu_baseline(model_name, cloud_np, budget_s, max_voxels=40000):
     from oracle import cpu_pipeline  # the CPU restatement: baseline only, never the product
-    m = randomize_(SparseFrontEnd(model_name).eval(), 0)
+    m = randomize_(SparseFrontEnd(model_name, max_voxels=max_voxels).eval(), 0)
     fps, iters, threads, times = cpu_pipeline.time_frontend(m, [cloud_np], budget_s=budget_s)
     return {"value": round(fps, 3), "unit": "frames/s", "cores": threads, "kind": "port",
             "host_cpus": os.cpu_count(),
@@ -138,6 +138,10 @@ def main():
     ap.add_argument("--model", default="M2", choices=["M1", "M2", "M3"])
     ap.add_argument("--points", type=int, default=20000)
     ap.add_argument("--frames", type=int, default=8, help="distinct synthetic frames cycled")
+    ap.add_argument("--shape", default="vkitti", choices=["vkitti", "synthia"],
+                    help="synthetic frame generator (synthia: BASELINE.json configs[4], use with "
+                         "--points 120000 --max-voxels 160000)")
+    ap.add_argument("--max-voxels", type=int, default=40000)
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--train-steps", type=int, default=10,
@@ -160,9 +164,10 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
-    model = randomize_(SparseFrontEnd(args.model).eval(), 0).to(dev)
+    model = randomize_(SparseFrontEnd(args.model, max_voxels=args.max_voxels).eval(), 0).to(dev)
+    gen = synth.vkitti_frame if args.shape == "vkitti" else synth.synthia_frame
     # each rank owns its own scenes (scene sharding): seeds rank*frames ... rank*frames+frames-1
-    clouds_np = [synth.vkitti_frame(rank * args.frames + i, args.points)
+    clouds_np = [gen(rank * args.frames + i, args.points)
                  for i in range(args.frames)]
     clouds = [torch.from_numpy(c).to(dev) for c in clouds_np]  # resident in HBM before timing
 
@@ -226,11 +231,13 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"{args.model}: one {args.points}-point Virtual-KITTI-shaped "
+            "config": {"workload": f"{args.model}: one {args.points}-point "
+                                   f"{'Virtual-KITTI' if args.shape == 'vkitti' else 'SYNTHIA'}-shaped "
                                    "frame per step, 1600x1408x41 grid (0.05/0.05/0.1 m, T=5), "
                                    "voxelize + VFE + SpMiddleFHD forward + dense(), batch 1 "
                                    "(BASELINE.json configs[1])",
                        "model": args.model, "points_per_frame": args.points,
+                       "frame_shape": args.shape, "max_voxels": args.max_voxels,
                        "path": "eager modules" if args.eager else "FrameEngine (hipGraph replay)",
                        "frames_in_flight": 1 if args.eager else args.inflight,
                        "parallelism": f"replicas x{world} (scene-sharded, no collective)"},
@@ -240,7 +247,8 @@ def main():
         if train is not None:
             line["train"] = train
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args.model, clouds_np[0], args.cpu_budget)
+            line["cpu_baseline"] = cpu_baseline(args.model, clouds_np[0], args.cpu_budget,
+                                                args.max_voxels)
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()

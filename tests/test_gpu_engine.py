@@ -61,3 +61,18 @@ def test_engine_overflow_is_reported_and_replanned(cuda):
         out = eng.forward(big, sync=True)  # re-plans with larger capacities
         assert not eng.overflowed()
         assert torch.equal(out, model([big]))
+
+
+def test_engine_dense_120k_point_frame(cuda):
+    """BASELINE.json configs[4] size: a ~120k-point SYNTHIA-shaped frame (hash occupancy stress)
+    through the captured engine equals the module path bit for bit (M1: same kernels)."""
+    model = randomize_(SparseFrontEnd("M1", max_voxels=160000).eval(), 0).to(cuda)
+    c = torch.from_numpy(synth.synthia_frame(0, 120000)).to(cuda)
+    with torch.no_grad():
+        eng = model.engine(calib=[c])
+        out = eng.forward(c).clone()
+        eng.check()
+        ks = eng.counts()
+        ref = model([c])
+    assert ks[0] > 60000  # tens of thousands of voxels per level
+    assert torch.equal(out, ref)
