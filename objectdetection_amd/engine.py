@@ -10,9 +10,9 @@ MI355X form: every row count of the path (points, voxels, active sites of each l
 device memory.  liblcf's entry points take (capacity, device count) pairs (include/lcf.h), the
 buffers are allocated once for the capacities -- 288 GB of HBM makes generous capacities free --
 and the ~60 launches of a frame are captured into a hipGraph that is replayed per frame.
-The sparse middle is bit-identical to the module-by-module path (same kernels, same order); the
-three VFE Linear layers run on liblcf's fp32-MFMA row-wise linear kernel instead of a library
-GEMM, so M2 features agree to fp32 rounding (~1e-6 relative) rather than bit for bit.
+The result is bit-identical to the module-by-module path (same kernels, same order; both use the
+fused VFE kernel when its shape applies).  Rulebooks depend on coordinates only, so their whole
+chain runs on a side stream -- a second branch of the graph -- beside the feature path.
 
 Every internal buffer reset is a fill KERNEL (lcf_fill32), not hipMemsetAsync: on ROCm 7.2 a
 captured graph holding hipMemsetAsync nodes hung at its second replay on this path.
