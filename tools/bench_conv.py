@@ -37,34 +37,51 @@ def main():
             layers.append((f"{'subm' if conv.subm else 'conv'} {conv.in_channels}->"
                            f"{conv.out_channels} K={rb.k_out}", args, pairs))
             x = conv(x, _scale=scale, _shift=shift, _relu=True)
+    bf16_imgs = {}
+    mods_c = [m for m in mid.middle_conv if hasattr(m, "subm")]
+    for li, conv in enumerate(mods_c):
+        if ops.bf16_supported(conv.in_channels, conv.out_channels):
+            bf16_imgs[li] = ops.weight_image_bf16(conv.weight)
     torch.cuda.synchronize()
     reps, rounds = 10, 5
-    splits = [1, 32, 64]  # 1 = slab form; 32 / 64 = tile-compacted with that many rows per tile
+    splits = [1, 32, 64, "bf16"]  # 1 = slab; 32 / 64 = tile-compacted rows per tile; bf16 operands
     res = {}
     for r in range(rounds):
         for sp in splits:
-            L.lcf_set_option(1, 1 if sp == 1 else 2)
-            L.lcf_set_option(2, 0 if sp == 1 else sp)
+            if sp == "bf16":
+                L.lcf_set_option(1, 0)
+                L.lcf_set_option(2, 0)
+            else:
+                L.lcf_set_option(1, 1 if sp == 1 else 2)
+                L.lcf_set_option(2, 0 if sp == 1 else sp)
             for li, (name, args, pairs) in enumerate(layers):
-                ops.conv_forward(*args)
+                fwd = ops.conv_forward
+                if sp == "bf16":
+                    if not ops.bf16_supported(args[5], args[6]):
+                        res.setdefault((li, sp), []).append(float("nan"))
+                        continue
+                    fwd = ops.conv_forward_bf16
+                    args = (args[0], bf16_imgs[li]) + args[2:]
+                fwd(*args)
                 e0 = torch.cuda.Event(enable_timing=True)
                 e1 = torch.cuda.Event(enable_timing=True)
                 e0.record()
                 for _ in range(reps):
-                    ops.conv_forward(*args)
+                    fwd(*args)
                 e1.record()
                 e1.synchronize()
                 res.setdefault((li, sp), []).append(e0.elapsed_time(e1) / reps * 1e3)
     L.lcf_set_option(1, 0)
     L.lcf_set_option(2, 0)
     tot = {sp: 0.0 for sp in splits}
+    import math
     print(f"{'layer':34s} {'pairs':>8s} " + " ".join(f"impl{sp}:us/TF" .rjust(16) for sp in splits))
     for li, (name, args, pairs) in enumerate(layers):
         cin, cout = args[5], args[6]
         row = f"{name:34s} {pairs:8d} "
         for sp in splits:
             us = min(res[(li, sp)])
-            tot[sp] += us
+            tot[sp] += 0.0 if math.isnan(us) else us
             row += f"{us:9.1f}/{2.0 * pairs * cin * cout / us / 1e6:5.1f} "
         print(row)
     print("total us:", {sp: round(v, 1) for sp, v in tot.items()})
