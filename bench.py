@@ -156,11 +156,22 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal of the N > 1 control flow on a one-GPU box: LCF_REHEARSE=1 puts every rank on
+    # cuda:0 and uses gloo (never used for reported numbers)
+    rehearse = os.environ.get("LCF_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ.get("LCF_REHEARSE_DUMP", "100")),
+                                          exit=True)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 

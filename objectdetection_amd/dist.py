@@ -54,5 +54,12 @@ class FlatGradAllReduce:
         if world == 1:
             return None
         self.flat.div_(world)
+        if self.flat.is_cuda and dist.get_backend(self.group) == "gloo":
+            # rehearsal only (several ranks sharing one GPU over gloo): gloo's device path hangs
+            # on large ROCm tensors, so stage through the host.  RCCL ("nccl") reduces in place.
+            host = self.flat.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+            self.flat.copy_(host)
+            return None
         return dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group,
                                async_op=async_op)
