@@ -220,3 +220,35 @@ def test_reference_files_import_unmodified_on_the_dropin():
     ours.load_state_dict(ref_net.state_dict(), strict=True)
     blk = sys.modules["second.pytorch.models.resnet"].SparseBasicBlock(16, 16, indice_key="r")
     assert isinstance(blk, spconv.SparseModule)
+
+
+def test_rpn_and_engine_surface():
+    """RPNV2 (downstream consumer of the training-step measurement) has the reference's shapes,
+    state_dict keys and parameter count; FrameEngine refuses to run without a GPU."""
+    import pytest
+    from objectdetection_amd.rpn import RPNV2
+    from objectdetection_amd.engine import FrameEngine
+    from objectdetection_amd.frontend import SparseFrontEnd
+    m = RPNV2()
+    out = m(torch.zeros(1, 128, 8, 8))
+    assert out["box_preds"].shape == (1, 2, 8, 8, 7)
+    assert out["cls_preds"].shape == (1, 2, 8, 8, 1)
+    assert out["dir_cls_preds"].shape == (1, 2, 8, 8, 2)
+    keys = set(m.state_dict().keys())
+    assert {"blocks.0.1.weight", "deblocks.0.0.weight", "conv_cls.weight", "conv_box.bias",
+            "conv_dir_cls.weight"} <= keys
+    assert 0.85e6 < sum(p.numel() for p in m.parameters()) < 0.95e6  # SURVEY.md: ~0.91 M
+    with pytest.raises(RuntimeError):
+        FrameEngine(SparseFrontEnd("M1").eval())  # CPU model: no fallback
+
+
+def test_conv_math_switch():
+    from objectdetection_amd import ops
+    assert ops._CONV_MATH[0] == "f32"
+    with ops.conv_math("bf16"):
+        assert ops._CONV_MATH[0] == "bf16"
+    assert ops._CONV_MATH[0] == "f32"
+    assert ops.bf16_supported(64, 64) and not ops.bf16_supported(16, 64)
+    import pytest
+    with pytest.raises(ValueError):
+        ops.conv_math("fp8")
