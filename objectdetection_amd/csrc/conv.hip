@@ -347,7 +347,7 @@ static size_t tc_lds_bytes(int CIN, int COUT, int TR, int kvol, bool bf16 = fals
                     : (size_t)2 * TR * (CIN + 4) * 4;                     // A rows of one offset
     b += tc_max((size_t)(TR + 1) * (COUT + 4) * 4, (size_t)TR * kvol * 4); // tile | nbr tile
     b = (b + 15) & ~(size_t)15;
-    b += (size_t)(TR + 16) * kvol * 4;                                    // item entries
+    b += (size_t)TR * kvol * 4;             // item entries: pad16(cnt) <= TR per offset
     b += (size_t)64 * 4 * 3 + 16;                                         // cnt, gbase, soff, n
     return b;
 }
@@ -387,7 +387,7 @@ cv_tc_kernel(const float *__restrict__ feat, const float *__restrict__ wimg,
     size_t off = ABYTES + (otb > nlb ? otb : nlb);
     off = (off + 15) & ~(size_t)15;
     unsigned *ent = reinterpret_cast<unsigned *>(smem + off);    // [items][16] entries
-    int *cnt = reinterpret_cast<int *>(ent + (TR + 16) * kvol);  // [64] rows per offset
+    int *cnt = reinterpret_cast<int *>(ent + TR * kvol);         // [64] rows per offset
     int *gbase = cnt + 64;                                       // [64] first item of an offset
     int *soff = gbase + 64;                                      // [64] offset of step s
     int *nsteps_p = soff + 64;

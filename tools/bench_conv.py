@@ -15,6 +15,8 @@ from objectdetection_amd.spconv.modules import _bn_affine  # noqa: E402
 
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
+    if os.environ.get("LCF_LIB"):  # an experimental build of the library (timing ablations)
+        _lib.LIB_PATH = os.path.abspath(os.environ["LCF_LIB"])
     dev = torch.device("cuda:0")
     model = randomize_(SparseFrontEnd("M2").eval(), 0).to(dev)
     cloud = torch.from_numpy(synth.vkitti_frame(0, n) if n <= 40000 else
