@@ -46,11 +46,13 @@ int lcf_version(void);
  * LCF_OPT_CONV_SPLIT: how many waves share one 16-row tile of the indice_conv forward by
  * splitting its output columns: 1, 2 or 4; 0 (default) = choose from the row count. */
 #define LCF_OPT_CONV_SPLIT 0
-/* LCF_OPT_CONV_IMPL: forward kernel: 0 (default) = per shape (tile-compacted for >= 32 output
- * channels, slab form for 16), 1 = slab form wherever it applies, 2 = tile-compacted. */
+/* LCF_OPT_CONV_IMPL: forward kernel: 0 (default) = per shape (tile-compacted when both channel
+ * counts are >= 32, split-slab for thin layers with <= 32 output channels, slab form for the
+ * rest), 1 = slab form wherever it applies, 2 = tile-compacted, 3 = split-slab wherever it
+ * applies (<= 32 output channels). */
 #define LCF_OPT_CONV_IMPL 1
-/* LCF_OPT_CONV_TILE: output rows per workgroup of the tile-compacted forward: 32, 64 or
- * 0 (default) = choose from the row count. */
+/* LCF_OPT_CONV_TILE: output rows per workgroup of the tile-compacted forward: 16, 32 or
+ * 0 (default = 32). */
 #define LCF_OPT_CONV_TILE 2
 int lcf_set_option(int option, int value);
 

@@ -301,6 +301,217 @@ epilogue_:
 }
 
 
+// -------------------------------------------------------------------------- split-slab fwd
+// Thin layers (Cout <= 32: the first SECOND levels, 128->16, 16->16, 16->32) have few rows, few
+// neighbours per row and little arithmetic: what costs there is the serial chain of offsets, each
+// a global round trip, on a machine that the launch does not fill.  Here a workgroup owns ONE
+// 16-row slab and its four waves split the reduction instead of the rows or columns:
+//   * Cin >= 64: wave w takes a quarter of the input channels of every active offset,
+//   * Cin <  64: wave w takes every fourth active offset,
+// each wave walking its items on its own (operands straight into the MFMA fragments: lane
+// (row, q) reads consecutive channels of its row, W[o] fragments stream from the image in L2,
+// next item in flight behind this item's MFMAs; no barrier in the loop).  The four partial
+// 16 x Cout tiles meet in LDS once and are summed in a fixed order: deterministic, 4x the waves
+// of the slab form and 4x shorter chains.
+template <int CIN, int COUT>
+__global__ void __launch_bounds__(CV_BLOCK)
+cv_ss_kernel(const float *__restrict__ feat, const float *__restrict__ wimg,
+             const int *__restrict__ nbr, int k_cap, const int *__restrict__ k_dev, int kvol,
+             int cin, int cout, const float *__restrict__ scale,
+             const float *__restrict__ shift, int relu, float *__restrict__ out)
+{
+    const int k_out = lcf_count(k_cap, k_dev);
+    constexpr int KL = CIN / 4;               // k values per lane quarter (image convention)
+    constexpr int VW = KL < 4 ? KL : 4;
+    constexpr int SG = KL / VW;
+    constexpr int NT = COUT / 16;
+    constexpr int WELEMS = CIN * COUT;
+    constexpr bool KSPLIT = CIN >= 64;        // waves split the channels, else the offsets
+    constexpr int KW = KSPLIT ? KL / CV_WAVES : KL; // k values per lane handled by one wave
+    constexpr int A4 = KW >= 4 ? KW / 4 : 1;
+    const int row0 = blockIdx.x * 16;
+    if (row0 >= k_out) return;
+
+    extern __shared__ __align__(16) unsigned char smem[];
+    float *red = reinterpret_cast<float *>(smem);                          // [4][16][COUT]
+    int *nl = reinterpret_cast<int *>(smem + CV_WAVES * 16 * COUT * 4);    // [16][kvol]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int r16 = lane & 15;
+    const int q = lane >> 4;
+    {
+        const long long gb = (long long)row0 * kvol, gl = (long long)k_out * kvol;
+        for (int e = tid; e < 16 * kvol; e += CV_BLOCK) nl[e] = (gb + e < gl) ? nbr[gb + e] : -1;
+    }
+    __syncthreads();
+    // offsets with a neighbour in the slab: lane o scans the 16 rows of offset o
+    unsigned long long mask;
+    {
+        bool any = false;
+        if (lane < kvol) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) any |= nl[r * kvol + lane] >= 0;
+        }
+        mask = __ballot(any);
+        const unsigned mlo = __builtin_amdgcn_readfirstlane((unsigned)mask);
+        const unsigned mhi = __builtin_amdgcn_readfirstlane((unsigned)(mask >> 32));
+        mask = ((unsigned long long)mhi << 32) | mlo;
+    }
+    // next item of this wave (-1: none): every active offset, or every fourth starting at #wave
+    auto pop = [&]() -> int {
+        if (mask == 0ull) return -1;
+        const int o = __builtin_ctzll(mask);
+        mask &= mask - 1ull;
+        if constexpr (!KSPLIT) {
+#pragma unroll
+            for (int j = 1; j < CV_WAVES; ++j) mask &= mask - 1ull; // x & (x-1) of 0 stays 0
+        }
+        return o;
+    };
+    if constexpr (!KSPLIT) {
+        for (int j = 0; j < wave; ++j) mask &= mask - 1ull;
+    }
+    const int ks0 = KSPLIT ? wave * KW : 0; // first k (within the lane's slice) of this wave
+
+    const bool exact = (cin == CIN);
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    struct AFrag { float4 v[A4]; };
+    struct BFrag { float b[NT][KW]; };
+
+    auto gather = [&](int o) -> AFrag {
+        AFrag a;
+        const int id = nl[r16 * kvol + o];
+#pragma unroll
+        for (int i = 0; i < A4; ++i) a.v[i] = zero4;
+        if (id >= 0) {
+            const float *src = feat + (size_t)id * cin + q * KL + ks0;
+            if (exact) {
+                if constexpr (KW >= 4) {
+#pragma unroll
+                    for (int i = 0; i < A4; ++i) a.v[i] = reinterpret_cast<const float4 *>(src)[i];
+                } else if constexpr (KW == 2) {
+                    float2 x = *reinterpret_cast<const float2 *>(src);
+                    a.v[0].x = x.x;
+                    a.v[0].y = x.y;
+                } else {
+                    a.v[0].x = src[0];
+                }
+            } else {
+                float tmp[A4 * 4];
+#pragma unroll
+                for (int s = 0; s < A4 * 4; ++s)
+                    tmp[s] = (s < KW && q * KL + ks0 + s < cin) ? src[s] : 0.f;
+#pragma unroll
+                for (int i = 0; i < A4; ++i)
+                    a.v[i] = make_float4(tmp[4 * i], tmp[4 * i + 1], tmp[4 * i + 2], tmp[4 * i + 3]);
+            }
+        }
+        return a;
+    };
+    auto bload = [&](int o) -> BFrag {
+        BFrag w;
+        const float *wo = wimg + (size_t)o * WELEMS;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            if constexpr (VW == 4) {
+#pragma unroll
+                for (int j = 0; j < KW / 4; ++j) {
+                    const int sg = ks0 / 4 + j;
+                    float4 x = *reinterpret_cast<const float4 *>(
+                        wo + (((t * SG + sg) * 4 + q) * 16 + r16) * 4);
+                    w.b[t][j * 4 + 0] = x.x;
+                    w.b[t][j * 4 + 1] = x.y;
+                    w.b[t][j * 4 + 2] = x.z;
+                    w.b[t][j * 4 + 3] = x.w;
+                }
+            } else if constexpr (VW == 2) {
+                float2 x = *reinterpret_cast<const float2 *>(wo + ((t * 4 + q) * 16 + r16) * 2);
+                w.b[t][0] = x.x;
+                w.b[t][1] = x.y;
+            } else {
+                w.b[t][0] = wo[(t * 4 + q) * 16 + r16];
+            }
+        }
+        return w;
+    };
+    auto afloat = [&](const AFrag &a, int s) -> float {
+        const float4 x = a.v[s >> 2];
+        switch (s & 3) {
+        case 0: return x.x;
+        case 1: return x.y;
+        case 2: return x.z;
+        default: return x.w;
+        }
+    };
+
+    f32x4 acc[NT][2];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        acc[t][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        acc[t][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    int o = pop();
+    if (o >= 0) {
+        AFrag acur = gather(o);
+        BFrag bcur = bload(o);
+        for (;;) {
+            const int on = pop(); // wave-uniform
+            AFrag an = acur;
+            BFrag bn = bcur;
+            if (on >= 0) {
+                an = gather(on);
+                bn = bload(on);
+            }
+#pragma unroll
+            for (int s = 0; s < KW; ++s)
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    acc[t][s & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                        afloat(acur, s), bcur.b[t][s], acc[t][s & 1], 0, 0, 0);
+            if (on < 0) break;
+            acur = an;
+            bcur = bn;
+        }
+    }
+    // ---- partial tiles -> LDS.  C/D map: col = lane&15, row = q*4+reg
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            red[(wave * 16 + q * 4 + r) * COUT + t * 16 + r16] = acc[t][0][r] + acc[t][1][r];
+    __syncthreads();
+    // ---- fixed-order sum, (x*scale + shift), relu, coalesced store
+    for (int e = tid; e < 16 * COUT; e += CV_BLOCK) {
+        const int r = e / COUT, c = e % COUT;
+        const int row = row0 + r;
+        if (row < k_out && c < cout) {
+            float v = ((red[e] + red[16 * COUT + e]) + red[2 * 16 * COUT + e]) +
+                      red[3 * 16 * COUT + e];
+            if (scale) v *= scale[c];
+            if (shift) v += shift[c];
+            if (relu) v = fmaxf(v, 0.f);
+            out[(size_t)row * cout + c] = v;
+        }
+    }
+}
+
+template <int CIN, int COUT>
+static int cv_launch_ss(const float *feat, const float *wimg, const int *nbr, int k_out,
+                        const int *k_dev, int kvol, int cin, int cout, const float *scale,
+                        const float *shift, int relu, float *out, hipStream_t st)
+{
+    if constexpr (COUT <= 32) {
+        const size_t lds = (size_t)CV_WAVES * 16 * COUT * 4 + (size_t)16 * kvol * 4;
+        const int nb = (k_out + 15) / 16;
+        cv_ss_kernel<CIN, COUT><<<nb, CV_BLOCK, lds, st>>>(feat, wimg, nbr, k_out, k_dev, kvol, cin,
+                                                         cout, scale, shift, relu, out);
+        LCF_CHECK_LAUNCH();
+        return LCF_OK;
+    }
+    return LCF_ERR_UNSUPPORTED;
+}
+
 // -------------------------------------------------------------------------- tile-compacted fwd
 // Second-generation forward ("tc"): the workgroup owns a tile of TR (32 or 64) output rows.
 // For every kernel offset it COMPACTS the rows of the tile that have a neighbour at that offset
@@ -691,7 +902,7 @@ cv_tc_kernel(const float *__restrict__ feat, const float *__restrict__ wimg,
     }
 }
 
-static int g_tc_rows = 0; // LCF_OPT_CONV_TILE: 0 = choose from the row count, 32 or 64
+static int g_tc_rows = 0; // LCF_OPT_CONV_TILE: 0 = default (32), 16 or 32 rows per tile
 
 template <int CIN, int COUT, int TR, bool BF16 = false>
 static int cv_launch_tc_n(const float *feat, const float *wimg, const int *nbr, int k_cap,
@@ -735,12 +946,12 @@ static int cv_launch_tc(const float *feat, const float *wimg, const int *nbr, in
                         const int *k_dev, int kvol, int cin, int cout, const float *scale,
                         const float *shift, int relu, float *out, hipStream_t st)
 {
-    // 64-row tiles halve the W traffic; 32-row tiles double the number of workgroups.
-    int tr = 32; // measured: 32-row tiles win on every SECOND layer (more, shorter workgroups)
-    if (g_tc_rows == 32 || g_tc_rows == 64) tr = g_tc_rows;
-    if (tr == 64 && tc_lds_bytes(CIN, COUT, 64, kvol) > 160 * 1024) tr = 32;
-    if (tr == 64)
-        return cv_launch_tc_n<CIN, COUT, 64>(feat, wimg, nbr, k_cap, k_dev, kvol, cin, cout,
+    // 32-row tiles by default (measured against 64-row tiles on every SECOND layer: more, shorter
+    // workgroups win); 16-row tiles are an option for thin layers with few rows.
+    int tr = 32;
+    if (g_tc_rows == 16 || g_tc_rows == 32) tr = g_tc_rows;
+    if (tr == 16)
+        return cv_launch_tc_n<CIN, COUT, 16>(feat, wimg, nbr, k_cap, k_dev, kvol, cin, cout,
                                              scale, shift, relu, out, st);
     return cv_launch_tc_n<CIN, COUT, 32>(feat, wimg, nbr, k_cap, k_dev, kvol, cin, cout, scale,
                                          shift, relu, out, st);
@@ -1020,7 +1231,7 @@ static int cv_launch_fwd_n(const float *feat, const float *wimg, const int *nbr,
 
 // Tuning knob (lcf_set_option(LCF_OPT_CONV_SPLIT, 1|2|4)); 0 = pick by size.
 static int g_conv_split = 0;
-static int g_conv_impl = 0; // 0 = choose per shape, 1 = slab form, 2 = tile-compacted
+static int g_conv_impl = 0; // 0 = choose per shape, 1 = slab, 2 = tile-compacted, 3 = split-slab
 static int cv_split_override() { return g_conv_split; }
 
 extern "C" int lcf_set_option(int option, int value)
@@ -1031,12 +1242,12 @@ extern "C" int lcf_set_option(int option, int value)
         return LCF_OK;
     }
     if (option == LCF_OPT_CONV_IMPL) {
-        if (value < 0 || value > 2) return LCF_ERR_ARG;
+        if (value < 0 || value > 3) return LCF_ERR_ARG;
         g_conv_impl = value;
         return LCF_OK;
     }
     if (option == LCF_OPT_CONV_TILE) {
-        if (value != 0 && value != 32 && value != 64) return LCF_ERR_ARG;
+        if (value != 0 && value != 16 && value != 32) return LCF_ERR_ARG;
         g_tc_rows = value;
         return LCF_OK;
     }
@@ -1115,10 +1326,15 @@ extern "C" int lcf_indice_conv_fwd(const float *feat, const float *wimg, const i
     if (CIN < 0 || COUT < 0) return LCF_ERR_UNSUPPORTED;
     if (k_out == 0) return LCF_OK;
     hipStream_t st = (hipStream_t)stream;
-    // narrow layers (one column tile = one wave per workgroup, or < 32 inputs) stay on the slab form
+    // other narrow shapes (< 32 inputs with >= 64 outputs) stay on the slab form
     const bool slab_ok = nbr && CIN * COUT <= 8192;
     const bool use_slab = g_conv_impl == 1 ? slab_ok : (g_conv_impl == 2 ? false
                                                                         : slab_ok && (COUT < 32 || CIN < 32));
+    // thin layers: one 16-row slab per workgroup, waves split the reduction
+    if (nbr && COUT <= 32 && (g_conv_impl == 3 || (g_conv_impl == 0 && (COUT < 32 || CIN < 32)))) {
+        CV_DISPATCH(cv_launch_ss, feat, wimg, nbr, k_out, k_out_dev, kvol, cin, cout, scale,
+                    shift, relu, out, st);
+    }
     if (use_slab) {
         CV_DISPATCH(cv_launch_fwd, feat, wimg, nbr, k_out, k_out_dev, kvol, cin, cout, scale,
                     shift, relu, out, st);

@@ -46,12 +46,15 @@ def main():
             bf16_imgs[li] = ops.weight_image_bf16(conv.weight)
     torch.cuda.synchronize()
     reps, rounds = 10, 5
-    splits = [1, 32, 64, "bf16"]  # 1 = slab; 32 / 64 = tile-compacted rows per tile; bf16 operands
+    splits = [1, "wp", 32, "bf16"]  # 1 = slab; wp = wave-private; 32 = tile-compacted; bf16 operands
     res = {}
     for r in range(rounds):
         for sp in splits:
             if sp == "bf16":
                 L.lcf_set_option(1, 0)
+                L.lcf_set_option(2, 0)
+            elif sp == "wp":
+                L.lcf_set_option(1, 3)
                 L.lcf_set_option(2, 0)
             else:
                 L.lcf_set_option(1, 1 if sp == 1 else 2)
