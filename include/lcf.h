@@ -51,9 +51,17 @@ int lcf_version(void);
  * rest), 1 = slab form wherever it applies, 2 = tile-compacted, 3 = split-slab wherever it
  * applies (<= 32 output channels). */
 #define LCF_OPT_CONV_IMPL 1
-/* LCF_OPT_CONV_TILE: output rows per workgroup of the tile-compacted forward: 16, 32 or
- * 0 (default = 32). */
+/* LCF_OPT_CONV_TILE: output rows per workgroup of the tile-compacted forward: 32 or 0
+ * (default, = 32); 16- and 64-row tiles were measured slower and are no longer built. */
 #define LCF_OPT_CONV_TILE 2
+/* LCF_OPT_CONV_SETS: wave sets per workgroup of the tile-compacted forward (a second set takes
+ * every other kernel offset of the tile): 1, 2 or 0 (default) = two when every tile of the
+ * launch is resident at once, judged from the row capacity passed to the call. */
+#define LCF_OPT_CONV_SETS 3
+/* LCF_OPT_CONV_ROWS_HINT: the number of output rows the following forward calls expect, for
+ * callers that pass a capacity as k_out and keep the real count on the device; only kernel
+ * selection reads it (never bounds).  0 (default) = use the k_out passed to the call. */
+#define LCF_OPT_CONV_ROWS_HINT 4
 int lcf_set_option(int option, int value);
 
 /* ------------------------------------------------------------------------------------------

@@ -66,6 +66,9 @@ SYMBOLS = {
                               c_int] + [c_void_p] * 11),
 }
 
+# lcf_set_option keys (include/lcf.h)
+OPT_CONV_SPLIT, OPT_CONV_IMPL, OPT_CONV_TILE, OPT_CONV_SETS, OPT_CONV_ROWS_HINT = 0, 1, 2, 3, 4
+
 _lib = None
 
 

@@ -552,11 +552,12 @@ struct TcCfg {
 
 static size_t tc_max(size_t a, size_t b) { return a > b ? a : b; }
 
-static size_t tc_lds_bytes(int CIN, int COUT, int TR, int kvol, bool bf16 = false)
+static size_t tc_lds_bytes(int CIN, int COUT, int TR, int kvol, bool bf16 = false, int nsets = 1)
 {
-    size_t b = bf16 ? (size_t)2 * TR * (CIN + 8) * 2                      // A rows, bf16
-                    : (size_t)2 * TR * (CIN + 4) * 4;                     // A rows of one offset
-    b += tc_max((size_t)(TR + 1) * (COUT + 4) * 4, (size_t)TR * kvol * 4); // tile | nbr tile
+    const int abufs = nsets == 1 ? 2 : 1; // one wave set double-buffers its rows, two do not
+    size_t b = bf16 ? (size_t)nsets * abufs * TR * (CIN + 8) * 2          // A rows, bf16
+                    : (size_t)nsets * abufs * TR * (CIN + 4) * 4;         // A rows of one offset
+    b += tc_max((size_t)nsets * (TR + 1) * (COUT + 4) * 4, (size_t)TR * kvol * 4); // tiles | nbr
     b = (b + 15) & ~(size_t)15;
     b += (size_t)TR * kvol * 4;             // item entries: pad16(cnt) <= TR per offset
     b += (size_t)64 * 4 * 3 + 16;                                         // cnt, gbase, soff, n
@@ -568,8 +569,11 @@ static size_t tc_lds_bytes(int CIN, int COUT, int TR, int kvol, bool bf16 = fals
 // BF16: operands rounded to bf16 (features when they enter LDS, weights in a bf16 image in
 // v_mfma_f32_16x16x32_bf16 fragment order), fp32 accumulation and fp32 output: the training
 // variant BASELINE.json configs[2] names.  Needs Cin a multiple of 32.
-template <int CIN, int COUT, int TR, bool EXACT, bool BF16>
-__global__ void __launch_bounds__(TC_THREADS(COUT))
+// NSETS = 2: a second set of waves takes every other step (offset), with its own row buffer and
+// its own output tile; the two tiles are summed (set 0 + set 1) in the epilogue.  Halves the
+// serial chain of a tile, which is what bounds layers with few tiles per CU.
+template <int CIN, int COUT, int TR, bool EXACT, bool BF16, int NSETS>
+__global__ void __launch_bounds__(TC_THREADS(COUT) * NSETS)
 cv_tc_kernel(const float *__restrict__ feat, const float *__restrict__ wimg,
              const int *__restrict__ nbr, int k_cap, const int *__restrict__ k_dev, int kvol,
              int cin, int cout, const float *__restrict__ scale,
@@ -581,6 +585,10 @@ cv_tc_kernel(const float *__restrict__ feat, const float *__restrict__ wimg,
     constexpr int WELEMS = C::WELEMS, MAXG = C::MAXG;
     constexpr bool AFULL = (ACH % THREADS) == 0;
     constexpr int DUMP = TR; // output-tile row that absorbs a group's padding entries
+    constexpr int ABUFS = NSETS == 1 ? 2 : 1;   // row buffers per wave set
+    constexpr int TT = THREADS * NSETS;         // threads of the workgroup
+    constexpr int NWT = C::NW * NSETS;          // waves of the workgroup
+    constexpr int OTE = (TR + 1) * OSTR;        // floats of one output tile
 
     const int k_out = lcf_count(k_cap, k_dev);
     const int row0 = blockIdx.x * TR;
@@ -589,12 +597,11 @@ cv_tc_kernel(const float *__restrict__ feat, const float *__restrict__ wimg,
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int ASTRH = CIN + 8;                               // bf16 A row stride (halfs)
     constexpr int KS = CIN >= 32 ? CIN / 32 : 1;                 // bf16 k-steps of 32
-    constexpr size_t ABYTES = BF16 ? (size_t)2 * TR * ASTRH * 2 : (size_t)2 * TR * ASTR * 4;
-    float *al = reinterpret_cast<float *>(smem);                 // [2][TR][ASTR]  (fp32 form)
-    __bf16 *alh = reinterpret_cast<__bf16 *>(smem);              // [2][TR][ASTRH] (bf16 form)
-    float *ot = reinterpret_cast<float *>(smem + ABYTES);        // [TR + dump row][OSTR]
-    int *nl = reinterpret_cast<int *>(ot);                       // [TR][kvol], dead before ot lives
-    size_t otb = (size_t)(TR + 1) * OSTR * 4, nlb = (size_t)TR * kvol * 4;
+    constexpr size_t ABYTES = BF16 ? (size_t)NSETS * ABUFS * TR * ASTRH * 2
+                                   : (size_t)NSETS * ABUFS * TR * ASTR * 4;
+    float *ot0 = reinterpret_cast<float *>(smem + ABYTES);       // [NSETS][TR + dump row][OSTR]
+    int *nl = reinterpret_cast<int *>(ot0);                      // [TR][kvol], dead before ot lives
+    size_t otb = (size_t)NSETS * OTE * 4, nlb = (size_t)TR * kvol * 4;
     size_t off = ABYTES + (otb > nlb ? otb : nlb);
     off = (off + 15) & ~(size_t)15;
     unsigned *ent = reinterpret_cast<unsigned *>(smem + off);    // [items][16] entries
@@ -603,18 +610,24 @@ cv_tc_kernel(const float *__restrict__ feat, const float *__restrict__ wimg,
     int *soff = gbase + 64;                                      // [64] offset of step s
     int *nsteps_p = soff + 64;
 
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6; // = column slice
+    const int tidw = threadIdx.x;          // thread of the workgroup
+    const int lane = tidw & 63;
+    const int wavew = tidw >> 6;           // wave of the workgroup
+    const int set = wavew / C::NW;         // wave set (0 when NSETS == 1)
+    const int wave = wavew % C::NW;        // = column slice
+    const int tid = tidw - set * THREADS;  // thread of the set
     const int r16 = lane & 15;
     const int q = lane >> 4;
+    float *al = reinterpret_cast<float *>(smem) + set * ABUFS * TR * ASTR;    // [ABUFS][TR][ASTR]
+    __bf16 *alh = reinterpret_cast<__bf16 *>(smem) + set * ABUFS * TR * ASTRH; // bf16 form
+    float *ot = ot0 + set * OTE;                                 // this set's output tile
 
     // ---- neighbour tile -> LDS (coalesced; rows past k_out read as -1)
     {
         const int total = TR * kvol;
         const long long gbase_e = (long long)row0 * kvol;
         const long long glimit = (long long)k_out * kvol;
-        for (int e = tid; e < total; e += THREADS) {
+        for (int e = tidw; e < total; e += TT) {
             int v = -1;
             if (gbase_e + e < glimit) v = nbr ? nbr[gbase_e + e] : row0 + e; // NULL: identity
             nl[e] = v;
@@ -622,13 +635,13 @@ cv_tc_kernel(const float *__restrict__ feat, const float *__restrict__ wimg,
     }
     __syncthreads();
     // ---- rows per offset
-    for (int o = wave; o < kvol; o += C::NW) {
+    for (int o = wavew; o < kvol; o += NWT) {
         const unsigned long long m = __ballot(lane < TR && nl[lane * kvol + o] >= 0);
         if (lane == 0) cnt[o] = __popcll(m);
     }
     __syncthreads();
     // ---- steps = active offsets ascending; items = their 16-row groups
-    if (wave == 0) {
+    if (wavew == 0) {
         const int c = lane < kvol ? cnt[lane] : 0;
         const int ng = (c + 15) >> 4;
         int incl = ng, sincl = c > 0 ? 1 : 0;
@@ -648,7 +661,7 @@ cv_tc_kernel(const float *__restrict__ feat, const float *__restrict__ wimg,
     __syncthreads();
     // ---- item entries: (input row << 7 | output row of the tile); a group's padding entries
     //      gather a valid row and dump the result
-    for (int o = wave; o < kvol; o += C::NW) {
+    for (int o = wavew; o < kvol; o += NWT) {
         const int id = lane < TR ? nl[lane * kvol + o] : -1;
         const bool has = id >= 0;
         const unsigned long long m = __ballot(has);
@@ -662,7 +675,7 @@ cv_tc_kernel(const float *__restrict__ feat, const float *__restrict__ wimg,
         if (c + lane < padded) dst[c + lane] = ((unsigned)first << 7) | (unsigned)DUMP;
     }
     __syncthreads();
-    for (int e = tid; e < (TR + 1) * OSTR; e += THREADS) ot[e] = 0.f; // nl is dead now
+    for (int e = tidw; e < NSETS * OTE; e += TT) ot0[e] = 0.f; // nl is dead now
     const int n_steps = *nsteps_p;
     __syncthreads();
 
@@ -832,30 +845,35 @@ cv_tc_kernel(const float *__restrict__ feat, const float *__restrict__ wimg,
     };
 
     if (n_steps > 0) {
-        int o = soff[0];
-        int i0 = gbase[o], ng = (cnt[o] + 15) >> 4;
+        // set j walks steps j, j + NSETS, ...; the workgroup walks them in lockstep rounds
+        const int n_rounds = (n_steps + NSETS - 1) / NSETS;
+        int s = set;
+        int o = soff[s < n_steps ? s : 0];
+        int i0 = gbase[o], ng = s < n_steps ? (cnt[o] + 15) >> 4 : 0;
         BReg bcur = bload(o);
         {
             AReg a0 = agather(i0, ng);
             astore(0, a0, ng);
         }
         __syncthreads();
-        for (int s = 0; s < n_steps; ++s) {
-            const bool more = s + 1 < n_steps; // workgroup-uniform
+        for (int u = 0; u < n_rounds; ++u, s += NSETS) {
+            const bool more = s + NSETS < n_steps; // uniform over the set
             BReg bnext = bcur;
             AReg an;
             int on = o, i0n = i0, ngn = 0;
             if (more) {
-                on = soff[s + 1];
+                on = soff[s + NSETS];
                 i0n = gbase[on];
                 ngn = (cnt[on] + 15) >> 4;
                 bnext = bload(on);
                 an = agather(i0n, ngn);
             }
+            const int abuf = ABUFS == 2 ? (u & 1) : 0;
 #pragma unroll
             for (int g = 0; g < MAXG; ++g)
-                if (g < ng) compute(s & 1, g, bcur, i0 + g);
-            if (more) astore((s + 1) & 1, an, ngn);
+                if (g < ng) compute(abuf, g, bcur, i0 + g);
+            if constexpr (ABUFS == 1) __syncthreads(); // single buffer: everyone done reading
+            if (more) astore(ABUFS == 2 ? ((u + 1) & 1) : 0, an, ngn);
             __syncthreads();
             bcur = bnext;
             o = on;
@@ -867,11 +885,16 @@ cv_tc_kernel(const float *__restrict__ feat, const float *__restrict__ wimg,
     // ---- epilogue: (x*scale + shift), relu, coalesced store of the tile
     if (cout == COUT) {
         constexpr int C4 = COUT / 4;
-        for (int e = tid; e < TR * C4; e += THREADS) {
+        for (int e = tidw; e < TR * C4; e += TT) {
             const int r = e / C4, c4 = e % C4;
             const int row = row0 + r;
             if (row < k_out) {
-                float4 v = *reinterpret_cast<const float4 *>(ot + r * OSTR + c4 * 4);
+                float4 v = *reinterpret_cast<const float4 *>(ot0 + r * OSTR + c4 * 4);
+                if constexpr (NSETS == 2) {
+                    const float4 v1 =
+                        *reinterpret_cast<const float4 *>(ot0 + OTE + r * OSTR + c4 * 4);
+                    v.x += v1.x; v.y += v1.y; v.z += v1.z; v.w += v1.w;
+                }
                 if (scale) {
                     const float4 s = *reinterpret_cast<const float4 *>(scale + c4 * 4);
                     v.x *= s.x; v.y *= s.y; v.z *= s.z; v.w *= s.w;
@@ -888,11 +911,12 @@ cv_tc_kernel(const float *__restrict__ feat, const float *__restrict__ wimg,
             }
         }
     } else {
-        for (int e = tid; e < TR * cout; e += THREADS) {
+        for (int e = tidw; e < TR * cout; e += TT) {
             const int r = e / cout, c = e % cout;
             const int row = row0 + r;
             if (row < k_out) {
-                float v = ot[r * OSTR + c];
+                float v = ot0[r * OSTR + c];
+                if constexpr (NSETS == 2) v += ot0[OTE + r * OSTR + c];
                 if (scale) v *= scale[c];
                 if (shift) v += shift[c];
                 if (relu) v = fmaxf(v, 0.f);
@@ -902,24 +926,26 @@ cv_tc_kernel(const float *__restrict__ feat, const float *__restrict__ wimg,
     }
 }
 
-static int g_tc_rows = 0; // LCF_OPT_CONV_TILE: 0 = default (32), 16 or 32 rows per tile
+static int g_tc_rows = 0; // LCF_OPT_CONV_TILE: 0 or 32 (the only tile height built)
+static int g_tc_sets = 0; // LCF_OPT_CONV_SETS: 0 = choose from the row count, 1 or 2 wave sets
+static int g_rows_hint = 0; // LCF_OPT_CONV_ROWS_HINT: expected rows (0 = the capacity passed)
 
-template <int CIN, int COUT, int TR, bool BF16 = false>
+template <int CIN, int COUT, int TR, bool BF16 = false, int NSETS = 1>
 static int cv_launch_tc_n(const float *feat, const float *wimg, const int *nbr, int k_cap,
                           const int *k_dev, int kvol, int cin, int cout, const float *scale,
                           const float *shift, int relu, float *out, hipStream_t st)
 {
     using C = TcCfg<CIN, COUT, TR>;
-    size_t lds = tc_lds_bytes(CIN, COUT, TR, kvol, BF16);
+    size_t lds = tc_lds_bytes(CIN, COUT, TR, kvol, BF16, NSETS);
     if (lds > 160 * 1024) return LCF_ERR_UNSUPPORTED;
     static size_t lds_set = 0; // per instantiation: largest dynamic LDS size opted into so far
     if (lds > 64 * 1024 && lds > lds_set) {
-        if (hipFuncSetAttribute((const void *)cv_tc_kernel<CIN, COUT, TR, true, BF16>,
+        if (hipFuncSetAttribute((const void *)cv_tc_kernel<CIN, COUT, TR, true, BF16, NSETS>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds) != hipSuccess)
             return LCF_ERR_LAUNCH;
         if constexpr (!BF16) {
-            if (hipFuncSetAttribute((const void *)cv_tc_kernel<CIN, COUT, TR, false, false>,
+            if (hipFuncSetAttribute((const void *)cv_tc_kernel<CIN, COUT, TR, false, false, NSETS>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)lds) != hipSuccess)
                 return LCF_ERR_LAUNCH;
@@ -927,18 +953,31 @@ static int cv_launch_tc_n(const float *feat, const float *wimg, const int *nbr, 
         lds_set = lds;
     }
     int nb = (k_cap + TR - 1) / TR;
+    constexpr int TT = C::THREADS * NSETS;
     if constexpr (BF16) {
         if (cin != CIN) return LCF_ERR_UNSUPPORTED;
-        cv_tc_kernel<CIN, COUT, TR, true, true><<<nb, C::THREADS, lds, st>>>(
+        cv_tc_kernel<CIN, COUT, TR, true, true, NSETS><<<nb, TT, lds, st>>>(
             feat, wimg, nbr, k_cap, k_dev, kvol, cin, cout, scale, shift, relu, out);
     } else if (cin == CIN)
-        cv_tc_kernel<CIN, COUT, TR, true, false><<<nb, C::THREADS, lds, st>>>(
+        cv_tc_kernel<CIN, COUT, TR, true, false, NSETS><<<nb, TT, lds, st>>>(
             feat, wimg, nbr, k_cap, k_dev, kvol, cin, cout, scale, shift, relu, out);
     else
-        cv_tc_kernel<CIN, COUT, TR, false, false><<<nb, C::THREADS, lds, st>>>(
+        cv_tc_kernel<CIN, COUT, TR, false, false, NSETS><<<nb, TT, lds, st>>>(
             feat, wimg, nbr, k_cap, k_dev, kvol, cin, cout, scale, shift, relu, out);
     LCF_CHECK_LAUNCH();
     return LCF_OK;
+}
+
+// Two wave sets pay when every tile of the launch is resident at once (the chain of a tile, not
+// the number of slots, is then what bounds the launch): workgroups per CU by LDS and by waves
+// (6 per SIMD at this register count) x 256 CUs against the number of tiles.
+static bool tc_two_sets_fit(int CIN, int COUT, int TR, int kvol, int k_cap)
+{
+    const int nw = (COUT / 16 >= 4 ? 4 : COUT / 16) * 2;
+    const size_t lds = tc_lds_bytes(CIN, COUT, TR, kvol, false, 2);
+    int per_cu = (int)((size_t)160 * 1024 / lds);
+    if (24 / nw < per_cu) per_cu = 24 / nw;
+    return (long long)per_cu * 256 >= (k_cap + TR - 1) / TR;
 }
 
 template <int CIN, int COUT>
@@ -946,13 +985,13 @@ static int cv_launch_tc(const float *feat, const float *wimg, const int *nbr, in
                         const int *k_dev, int kvol, int cin, int cout, const float *scale,
                         const float *shift, int relu, float *out, hipStream_t st)
 {
-    // 32-row tiles by default (measured against 64-row tiles on every SECOND layer: more, shorter
-    // workgroups win); 16-row tiles are an option for thin layers with few rows.
-    int tr = 32;
-    if (g_tc_rows == 16 || g_tc_rows == 32) tr = g_tc_rows;
-    if (tr == 16)
-        return cv_launch_tc_n<CIN, COUT, 16>(feat, wimg, nbr, k_cap, k_dev, kvol, cin, cout,
-                                             scale, shift, relu, out, st);
+    // 32-row tiles: measured against 16- and 64-row tiles on every SECOND layer (64: half the
+    // workgroups with the same serial chain; 16: more MFMA padding, same chain).
+    const int rows = g_rows_hint > 0 && g_rows_hint < k_cap ? g_rows_hint : k_cap;
+    const bool two = g_tc_sets == 2 || (g_tc_sets == 0 && tc_two_sets_fit(CIN, COUT, 32, kvol, rows));
+    if (two && tc_lds_bytes(CIN, COUT, 32, kvol, false, 2) <= 160 * 1024)
+        return cv_launch_tc_n<CIN, COUT, 32, false, 2>(feat, wimg, nbr, k_cap, k_dev, kvol, cin,
+                                                       cout, scale, shift, relu, out, st);
     return cv_launch_tc_n<CIN, COUT, 32>(feat, wimg, nbr, k_cap, k_dev, kvol, cin, cout, scale,
                                          shift, relu, out, st);
 }
@@ -1246,8 +1285,18 @@ extern "C" int lcf_set_option(int option, int value)
         g_conv_impl = value;
         return LCF_OK;
     }
+    if (option == LCF_OPT_CONV_ROWS_HINT) {
+        if (value < 0) return LCF_ERR_ARG;
+        g_rows_hint = value;
+        return LCF_OK;
+    }
+    if (option == LCF_OPT_CONV_SETS) {
+        if (value < 0 || value > 2) return LCF_ERR_ARG;
+        g_tc_sets = value;
+        return LCF_OK;
+    }
     if (option == LCF_OPT_CONV_TILE) {
-        if (value != 0 && value != 16 && value != 32) return LCF_ERR_ARG;
+        if (value != 0 && value != 32) return LCF_ERR_ARG;
         g_tc_rows = value;
         return LCF_OK;
     }

@@ -82,6 +82,7 @@ class FrameEngine:
         self.level_caps = None
         # plan with worst-case-ish capacities, measure, then re-plan tight and capture
         self._plan(None)
+        self.level_need = None  # rows per level seen in calibration (kernel-selection hint)
         if calib:
             need = None
             for c in calib:
@@ -91,6 +92,7 @@ class FrameEngine:
                 if self.overflowed():
                     raise RuntimeError("FrameEngine: calibration frame exceeds the loose caps")
                 need = ks if need is None else [max(a, b) for a, b in zip(need, ks)]
+            self.level_need = list(need)
             self._plan([_round_up(self.margin * k + 2048, 1024) for k in need[1:]])
         if use_graph:
             self._capture()
@@ -308,6 +310,7 @@ class FrameEngine:
                                  self.layers[0].cin, P(self.feat0), st))
         feat, coors = self.feat0, self.coors
         waited = set()
+        lvl = 0
         for l in self.layers:
             o = l.rb_owner
             if self.two_streams and id(o) not in waited:
@@ -317,12 +320,17 @@ class FrameEngine:
                 k_out_cap, k_out_dev = l.k_in_cap, kd
             else:
                 k_out_cap, k_out_dev = l.k_out_cap, l.k_out
+                lvl += 1
+            # the launch is sized by the capacity; the kernel variant by the rows expected
+            need = self.level_need
+            L.lcf_set_option(_lib.OPT_CONV_ROWS_HINT, int(need[lvl]) if need else 0)
             check(L.lcf_indice_conv_fwd(P(feat), P(l.wimg), P(o.nbr), k_out_cap, P(k_out_dev),
                                         l.kvol, l.cin, l.cout, P(l.scale), P(l.shift),
                                         int(l.relu), P(l.out), st))
             feat = l.out
             if not l.subm:
                 coors, kd = l.out_coors, l.k_out
+        L.lcf_set_option(_lib.OPT_CONV_ROWS_HINT, 0)
         if self.two_streams:
             main.wait_event(e_dense)  # also joins the side stream (its last operation)
         check(L.lcf_dense(P(feat), P(coors), feat.shape[0], P(kd), feat.shape[1], 1,

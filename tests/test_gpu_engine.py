@@ -1,12 +1,28 @@
 """GPU: the graph-captured FrameEngine (no host sync, device-side row counts) reproduces the
 module-by-module path bit for bit, across frames of different sizes, and reports overflow."""
+import contextlib
+
 import pytest
 import torch
 
-from objectdetection_amd import synth
+from objectdetection_amd import _lib, synth
 from objectdetection_amd.frontend import SparseFrontEnd, randomize_
 
 pytestmark = pytest.mark.gpu
+
+
+@contextlib.contextmanager
+def one_wave_set():
+    """The forward picks one or two wave sets per layer from the row count it expects (the
+    engine: calibrated, frozen in the graph; the module path: the frame's own), and the two sum
+    the kernel offsets in a different order.  Pinned to one set, both paths run the same
+    kernels and must agree bit for bit."""
+    L = _lib.lib()
+    L.lcf_set_option(_lib.OPT_CONV_SETS, 1)
+    try:
+        yield
+    finally:
+        L.lcf_set_option(_lib.OPT_CONV_SETS, 0)
 
 
 def _clouds(cuda, seeds, n):
@@ -17,7 +33,7 @@ def _clouds(cuda, seeds, n):
 def test_engine_matches_eager(cuda, name):
     model = randomize_(SparseFrontEnd(name).eval(), 0).to(cuda)
     calib = _clouds(cuda, [0, 1], 20000)
-    with torch.no_grad():
+    with torch.no_grad(), one_wave_set():
         eng = model.engine(calib=calib)
         # frames of different sizes through the SAME captured graph, in arbitrary order
         for seed, n in [(0, 20000), (5, 12000), (1, 20000), (7, 3000), (5, 12000)]:
@@ -38,7 +54,7 @@ def test_engine_matches_eager(cuda, name):
 
 def test_engine_without_graph_and_empty_frame(cuda):
     model = randomize_(SparseFrontEnd("M1").eval(), 0).to(cuda)
-    with torch.no_grad():
+    with torch.no_grad(), one_wave_set():
         eng = model.engine(calib=_clouds(cuda, [0], 8000), use_graph=False)
         c = _clouds(cuda, [3], 8000)[0]
         assert torch.equal(eng.forward(c), model([c]))
@@ -52,7 +68,7 @@ def test_engine_overflow_is_reported_and_replanned(cuda):
     model = randomize_(SparseFrontEnd("M1").eval(), 0).to(cuda)
     small = _clouds(cuda, [0], 1500)
     big = _clouds(cuda, [1], 30000)[0]
-    with torch.no_grad():
+    with torch.no_grad(), one_wave_set():
         eng = model.engine(calib=small, max_points=40000, margin=1.0)
         eng.forward(big)
         assert eng.overflowed()
@@ -68,7 +84,7 @@ def test_engine_dense_120k_point_frame(cuda):
     through the captured engine equals the module path bit for bit (M1: same kernels)."""
     model = randomize_(SparseFrontEnd("M1", max_voxels=160000).eval(), 0).to(cuda)
     c = torch.from_numpy(synth.synthia_frame(0, 120000)).to(cuda)
-    with torch.no_grad():
+    with torch.no_grad(), one_wave_set():
         eng = model.engine(calib=[c])
         out = eng.forward(c).clone()
         eng.check()
@@ -76,3 +92,22 @@ def test_engine_dense_120k_point_frame(cuda):
         ref = model([c])
     assert ks[0] > 60000  # tens of thousands of voxels per level
     assert torch.equal(out, ref)
+
+
+@pytest.mark.parametrize("name", ["M1", "M2"])
+def test_engine_default_kernel_selection(cuda, name):
+    """Default selection (two wave sets where the calibrated row counts say every tile is
+    resident): engine and module path may then sum the offsets of a layer in a different order;
+    they agree to fp32 reassociation error, far inside the 1e-4 feature tolerance."""
+    model = randomize_(SparseFrontEnd(name).eval(), 0).to(cuda)
+    with torch.no_grad():
+        eng = model.engine(calib=_clouds(cuda, [0, 1], 20000))
+        for seed, n in [(0, 20000), (7, 3000), (2, 20000)]:
+            c = torch.from_numpy(synth.vkitti_frame(seed, n)).to(cuda)
+            out = eng.forward(c).clone()
+            eng.check()
+            ref = model([c])
+            err = (out - ref).abs().max() / ref.abs().max()
+            assert err.item() < (1e-5 if name == "M1" else 1e-4)
+            again = eng.forward(c)
+            assert torch.equal(out, again)  # each path by itself is run-to-run deterministic

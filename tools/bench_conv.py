@@ -46,19 +46,20 @@ def main():
             bf16_imgs[li] = ops.weight_image_bf16(conv.weight)
     torch.cuda.synchronize()
     reps, rounds = 10, 5
-    splits = [1, "wp", 32, "bf16"]  # 1 = slab; wp = wave-private; 32 = tile-compacted; bf16 operands
+    splits = [1, "ss", "tc1", "tc2", "bf16"]  # slab; split-slab; tile-compacted 1 / 2 wave sets; bf16
     res = {}
     for r in range(rounds):
         for sp in splits:
+            L.lcf_set_option(3, 0)
             if sp == "bf16":
                 L.lcf_set_option(1, 0)
-                L.lcf_set_option(2, 0)
-            elif sp == "wp":
+            elif sp == "ss":
                 L.lcf_set_option(1, 3)
-                L.lcf_set_option(2, 0)
+            elif sp == 1:
+                L.lcf_set_option(1, 1)
             else:
-                L.lcf_set_option(1, 1 if sp == 1 else 2)
-                L.lcf_set_option(2, 0 if sp == 1 else sp)
+                L.lcf_set_option(1, 2)
+                L.lcf_set_option(3, 1 if sp == "tc1" else 2)
             for li, (name, args, pairs) in enumerate(layers):
                 fwd = ops.conv_forward
                 if sp == "bf16":
@@ -77,10 +78,10 @@ def main():
                 e1.synchronize()
                 res.setdefault((li, sp), []).append(e0.elapsed_time(e1) / reps * 1e3)
     L.lcf_set_option(1, 0)
-    L.lcf_set_option(2, 0)
+    L.lcf_set_option(3, 0)
     tot = {sp: 0.0 for sp in splits}
     import math
-    print(f"{'layer':34s} {'pairs':>8s} " + " ".join(f"impl{sp}:us/TF" .rjust(16) for sp in splits))
+    print(f"{'layer':34s} {'pairs':>8s} " + " ".join(f"{sp}:us/TF" .rjust(16) for sp in splits))
     for li, (name, args, pairs) in enumerate(layers):
         cin, cout = args[5], args[6]
         row = f"{name:34s} {pairs:8d} "
