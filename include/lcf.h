@@ -51,8 +51,8 @@ int lcf_version(void);
  * rest), 1 = slab form wherever it applies, 2 = tile-compacted, 3 = split-slab wherever it
  * applies (<= 32 output channels). */
 #define LCF_OPT_CONV_IMPL 1
-/* LCF_OPT_CONV_TILE: output rows per workgroup of the tile-compacted forward: 32 or 0
- * (default, = 32); 16- and 64-row tiles were measured slower and are no longer built. */
+/* LCF_OPT_CONV_TILE: output rows per workgroup of the tile-compacted forward: 16..32, or 0
+ * (default) = the largest height <= 32 that deals the tiles evenly over the 256 CUs. */
 #define LCF_OPT_CONV_TILE 2
 /* LCF_OPT_CONV_SETS: wave sets per workgroup of the tile-compacted forward (a second set takes
  * every other kernel offset of the tile): 1, 2 or 0 (default) = two when every tile of the

@@ -577,7 +577,7 @@ __global__ void __launch_bounds__(TC_THREADS(COUT) * NSETS)
 cv_tc_kernel(const float *__restrict__ feat, const float *__restrict__ wimg,
              const int *__restrict__ nbr, int k_cap, const int *__restrict__ k_dev, int kvol,
              int cin, int cout, const float *__restrict__ scale,
-             const float *__restrict__ shift, int relu, float *__restrict__ out)
+             const float *__restrict__ shift, int relu, float *__restrict__ out, int tr)
 {
     using C = TcCfg<CIN, COUT, TR>;
     constexpr int THREADS = C::THREADS, NT = C::NT, KL = C::KL, VW = C::VW, SG = C::SG;
@@ -591,7 +591,9 @@ cv_tc_kernel(const float *__restrict__ feat, const float *__restrict__ wimg,
     constexpr int OTE = (TR + 1) * OSTR;        // floats of one output tile
 
     const int k_out = lcf_count(k_cap, k_dev);
-    const int row0 = blockIdx.x * TR;
+    // tr <= TR rows per tile (host: chosen so that the tiles divide evenly over the CUs); every
+    // buffer is laid out for TR rows
+    const int row0 = blockIdx.x * tr;
     if (row0 >= k_out) return;
 
     extern __shared__ __align__(16) unsigned char smem[];
@@ -624,7 +626,7 @@ cv_tc_kernel(const float *__restrict__ feat, const float *__restrict__ wimg,
 
     // ---- neighbour tile -> LDS (coalesced; rows past k_out read as -1)
     {
-        const int total = TR * kvol;
+        const int total = tr * kvol;
         const long long gbase_e = (long long)row0 * kvol;
         const long long glimit = (long long)k_out * kvol;
         for (int e = tidw; e < total; e += TT) {
@@ -636,7 +638,7 @@ cv_tc_kernel(const float *__restrict__ feat, const float *__restrict__ wimg,
     __syncthreads();
     // ---- rows per offset
     for (int o = wavew; o < kvol; o += NWT) {
-        const unsigned long long m = __ballot(lane < TR && nl[lane * kvol + o] >= 0);
+        const unsigned long long m = __ballot(lane < tr && nl[lane * kvol + o] >= 0);
         if (lane == 0) cnt[o] = __popcll(m);
     }
     __syncthreads();
@@ -662,7 +664,7 @@ cv_tc_kernel(const float *__restrict__ feat, const float *__restrict__ wimg,
     // ---- item entries: (input row << 7 | output row of the tile); a group's padding entries
     //      gather a valid row and dump the result
     for (int o = wavew; o < kvol; o += NWT) {
-        const int id = lane < TR ? nl[lane * kvol + o] : -1;
+        const int id = lane < tr ? nl[lane * kvol + o] : -1;
         const bool has = id >= 0;
         const unsigned long long m = __ballot(has);
         if (m == 0ull) continue;
@@ -885,7 +887,7 @@ cv_tc_kernel(const float *__restrict__ feat, const float *__restrict__ wimg,
     // ---- epilogue: (x*scale + shift), relu, coalesced store of the tile
     if (cout == COUT) {
         constexpr int C4 = COUT / 4;
-        for (int e = tidw; e < TR * C4; e += TT) {
+        for (int e = tidw; e < tr * C4; e += TT) {
             const int r = e / C4, c4 = e % C4;
             const int row = row0 + r;
             if (row < k_out) {
@@ -911,7 +913,7 @@ cv_tc_kernel(const float *__restrict__ feat, const float *__restrict__ wimg,
             }
         }
     } else {
-        for (int e = tidw; e < TR * cout; e += TT) {
+        for (int e = tidw; e < tr * cout; e += TT) {
             const int r = e / cout, c = e % cout;
             const int row = row0 + r;
             if (row < k_out) {
@@ -926,14 +928,14 @@ cv_tc_kernel(const float *__restrict__ feat, const float *__restrict__ wimg,
     }
 }
 
-static int g_tc_rows = 0; // LCF_OPT_CONV_TILE: 0 or 32 (the only tile height built)
+static int g_tc_rows = 0; // LCF_OPT_CONV_TILE: 0 = balance over the CUs, 16..32 = fixed height
 static int g_tc_sets = 0; // LCF_OPT_CONV_SETS: 0 = choose from the row count, 1 or 2 wave sets
 static int g_rows_hint = 0; // LCF_OPT_CONV_ROWS_HINT: expected rows (0 = the capacity passed)
 
 template <int CIN, int COUT, int TR, bool BF16 = false, int NSETS = 1>
 static int cv_launch_tc_n(const float *feat, const float *wimg, const int *nbr, int k_cap,
                           const int *k_dev, int kvol, int cin, int cout, const float *scale,
-                          const float *shift, int relu, float *out, hipStream_t st)
+                          const float *shift, int relu, float *out, hipStream_t st, int tr = TR)
 {
     using C = TcCfg<CIN, COUT, TR>;
     size_t lds = tc_lds_bytes(CIN, COUT, TR, kvol, BF16, NSETS);
@@ -952,32 +954,48 @@ static int cv_launch_tc_n(const float *feat, const float *wimg, const int *nbr, 
         }
         lds_set = lds;
     }
-    int nb = (k_cap + TR - 1) / TR;
+    if (tr < 1 || tr > TR) return LCF_ERR_ARG;
+    int nb = (k_cap + tr - 1) / tr;
     constexpr int TT = C::THREADS * NSETS;
     if constexpr (BF16) {
         if (cin != CIN) return LCF_ERR_UNSUPPORTED;
         cv_tc_kernel<CIN, COUT, TR, true, true, NSETS><<<nb, TT, lds, st>>>(
-            feat, wimg, nbr, k_cap, k_dev, kvol, cin, cout, scale, shift, relu, out);
+            feat, wimg, nbr, k_cap, k_dev, kvol, cin, cout, scale, shift, relu, out, tr);
     } else if (cin == CIN)
         cv_tc_kernel<CIN, COUT, TR, true, false, NSETS><<<nb, TT, lds, st>>>(
-            feat, wimg, nbr, k_cap, k_dev, kvol, cin, cout, scale, shift, relu, out);
+            feat, wimg, nbr, k_cap, k_dev, kvol, cin, cout, scale, shift, relu, out, tr);
     else
         cv_tc_kernel<CIN, COUT, TR, false, false, NSETS><<<nb, TT, lds, st>>>(
-            feat, wimg, nbr, k_cap, k_dev, kvol, cin, cout, scale, shift, relu, out);
+            feat, wimg, nbr, k_cap, k_dev, kvol, cin, cout, scale, shift, relu, out, tr);
     LCF_CHECK_LAUNCH();
     return LCF_OK;
+}
+
+// Rows per tile: the largest height <= 32 for which the tiles are a whole number of rounds over
+// the 256 CUs (581 tiles of 32 rows are 2 on most CUs and 3 on some, and the launch lasts as
+// long as the CUs with 3; 744 tiles of 25 rows are 3 everywhere, each 22% shorter).
+static int tc_tile_rows(int rows)
+{
+    if (g_tc_rows >= 16 && g_tc_rows <= 32) return g_tc_rows;
+    const int per_round = 256;
+    const int m = (rows + per_round * 32 - 1) / (per_round * 32); // tiles per CU at 32 rows
+    if (m < 1) return 32;
+    int tr = (rows + per_round * m - 1) / (per_round * m);
+    if (tr < 16) tr = 16;
+    if (tr > 32) tr = 32;
+    return tr;
 }
 
 // Two wave sets pay when every tile of the launch is resident at once (the chain of a tile, not
 // the number of slots, is then what bounds the launch): workgroups per CU by LDS and by waves
 // (6 per SIMD at this register count) x 256 CUs against the number of tiles.
-static bool tc_two_sets_fit(int CIN, int COUT, int TR, int kvol, int k_cap)
+static bool tc_two_sets_fit(int CIN, int COUT, int kvol, int rows, int tr)
 {
     const int nw = (COUT / 16 >= 4 ? 4 : COUT / 16) * 2;
-    const size_t lds = tc_lds_bytes(CIN, COUT, TR, kvol, false, 2);
+    const size_t lds = tc_lds_bytes(CIN, COUT, 32, kvol, false, 2);
     int per_cu = (int)((size_t)160 * 1024 / lds);
     if (24 / nw < per_cu) per_cu = 24 / nw;
-    return (long long)per_cu * 256 >= (k_cap + TR - 1) / TR;
+    return (long long)per_cu * 256 >= (rows + tr - 1) / tr;
 }
 
 template <int CIN, int COUT>
@@ -985,15 +1003,16 @@ static int cv_launch_tc(const float *feat, const float *wimg, const int *nbr, in
                         const int *k_dev, int kvol, int cin, int cout, const float *scale,
                         const float *shift, int relu, float *out, hipStream_t st)
 {
-    // 32-row tiles: measured against 16- and 64-row tiles on every SECOND layer (64: half the
-    // workgroups with the same serial chain; 16: more MFMA padding, same chain).
+    // tiles of up to 32 rows: measured against 64-row tiles on every SECOND layer (half the
+    // workgroups with the same serial chain lose)
     const int rows = g_rows_hint > 0 && g_rows_hint < k_cap ? g_rows_hint : k_cap;
-    const bool two = g_tc_sets == 2 || (g_tc_sets == 0 && tc_two_sets_fit(CIN, COUT, 32, kvol, rows));
+    const int tr = tc_tile_rows(rows);
+    const bool two = g_tc_sets == 2 || (g_tc_sets == 0 && tc_two_sets_fit(CIN, COUT, kvol, rows, tr));
     if (two && tc_lds_bytes(CIN, COUT, 32, kvol, false, 2) <= 160 * 1024)
         return cv_launch_tc_n<CIN, COUT, 32, false, 2>(feat, wimg, nbr, k_cap, k_dev, kvol, cin,
-                                                       cout, scale, shift, relu, out, st);
+                                                       cout, scale, shift, relu, out, st, tr);
     return cv_launch_tc_n<CIN, COUT, 32>(feat, wimg, nbr, k_cap, k_dev, kvol, cin, cout, scale,
-                                         shift, relu, out, st);
+                                         shift, relu, out, st, tr);
 }
 
 // -------------------------------------------------------------------------- bf16 entry points
@@ -1296,7 +1315,7 @@ extern "C" int lcf_set_option(int option, int value)
         return LCF_OK;
     }
     if (option == LCF_OPT_CONV_TILE) {
-        if (value != 0 && value != 32) return LCF_ERR_ARG;
+        if (value != 0 && (value < 16 || value > 32)) return LCF_ERR_ARG;
         g_tc_rows = value;
         return LCF_OK;
     }

@@ -46,11 +46,13 @@ def main():
             bf16_imgs[li] = ops.weight_image_bf16(conv.weight)
     torch.cuda.synchronize()
     reps, rounds = 10, 5
-    splits = [1, "ss", "tc1", "tc2", "bf16"]  # slab; split-slab; tile-compacted 1 / 2 wave sets; bf16
+    # slab; split-slab; tile-compacted: 1 set fixed 32-row tiles, 1 set, 2 sets (balanced tiles); bf16
+    splits = [1, "ss", "tc1_32", "tc1", "tc2", "bf16"]
     res = {}
     for r in range(rounds):
         for sp in splits:
             L.lcf_set_option(3, 0)
+            L.lcf_set_option(2, 32 if sp == "tc1_32" else 0)
             if sp == "bf16":
                 L.lcf_set_option(1, 0)
             elif sp == "ss":
@@ -59,7 +61,7 @@ def main():
                 L.lcf_set_option(1, 1)
             else:
                 L.lcf_set_option(1, 2)
-                L.lcf_set_option(3, 1 if sp == "tc1" else 2)
+                L.lcf_set_option(3, 2 if sp == "tc2" else 1)
             for li, (name, args, pairs) in enumerate(layers):
                 fwd = ops.conv_forward
                 if sp == "bf16":
@@ -78,6 +80,7 @@ def main():
                 e1.synchronize()
                 res.setdefault((li, sp), []).append(e0.elapsed_time(e1) / reps * 1e3)
     L.lcf_set_option(1, 0)
+    L.lcf_set_option(2, 0)
     L.lcf_set_option(3, 0)
     tot = {sp: 0.0 for sp in splits}
     import math
