@@ -62,6 +62,11 @@ int lcf_version(void);
  * callers that pass a capacity as k_out and keep the real count on the device; only kernel
  * selection reads it (never bounds).  0 (default) = use the k_out passed to the call. */
 #define LCF_OPT_CONV_ROWS_HINT 4
+/* LCF_OPT_WS_CLEAN: 1 = lcf_voxelize, lcf_rulebook_subm and lcf_rulebook_conv_discover skip the
+ * reset of their hash workspace: the caller guarantees it is in the reset state on entry
+ * (lcf_*_workspace_reset below, e.g. enqueued behind the previous frame, off its critical path);
+ * the calls leave it dirty.  0 (default) = every call resets its workspace itself. */
+#define LCF_OPT_WS_CLEAN 5
 int lcf_set_option(int option, int value);
 
 /* ------------------------------------------------------------------------------------------
@@ -81,6 +86,8 @@ int lcf_set_option(int option, int value);
  * that merge_second_batch (second/data/preprocess.py:44-50) pads on the host.
  */
 size_t lcf_voxelize_workspace_bytes(int n, int max_pts);
+/* Puts a workspace of lcf_voxelize(n, max_pts) into its reset state (see LCF_OPT_WS_CLEAN). */
+int lcf_voxelize_workspace_reset(void *ws, size_t ws_bytes, int n, int max_pts, void *stream);
 int lcf_voxelize(const float *points, int n, const int *n_dev, int f, const float vs[3],
                  const float range[6], int max_pts, int max_vox, int cap_mode, int batch_idx,
                  int coor_stride, float *voxels, int *coors, int *num_pts, int *voxel_num,
@@ -101,6 +108,7 @@ int lcf_voxelize(const float *points, int n, const int *n_dev, int f, const floa
  * coors [k,4] i32 (b,z,y,x).  shape/ksize/stride/pad/dil are HOST int[3] (z,y,x order).
  */
 size_t lcf_rulebook_subm_workspace_bytes(int k);
+int lcf_rulebook_subm_workspace_reset(void *ws, size_t ws_bytes, int k, void *stream);
 int lcf_rulebook_subm(const int *coors, int k, const int *k_dev, int batch, const int shape[3],
                       const int ksize[3], const int dil[3], int *out_nbr, void *ws,
                       size_t ws_bytes, void *stream);
@@ -119,6 +127,8 @@ int lcf_rulebook_conv_max_out(int k_in, const int ksize[3], const int stride[3])
 void lcf_conv_out_shape(const int shape[3], const int ksize[3], const int stride[3],
                         const int pad[3], const int dil[3], int out_shape[3]);
 size_t lcf_rulebook_conv_workspace_bytes(int k_in, const int ksize[3], const int stride[3]);
+int lcf_rulebook_conv_workspace_reset(void *ws, size_t ws_bytes, int k_in, const int ksize[3],
+                                      const int stride[3], void *stream);
 int lcf_rulebook_conv_discover(const int *coors, int k_in, const int *k_in_dev, int batch,
                                const int shape[3], const int ksize[3], const int stride[3],
                                const int pad[3], const int dil[3], int *out_coors, int cap_out,

@@ -22,15 +22,19 @@ SYMBOLS = {
     "lcf_version": (c_int, []),
     "lcf_set_option": (c_int, [c_int, c_int]),
     "lcf_voxelize_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "lcf_voxelize_workspace_reset": (c_int, [c_void_p, c_size_t, c_int, c_int, c_void_p]),
     "lcf_voxelize": (c_int, [c_void_p, c_int, c_void_p, c_int, _PF, _PF, c_int, c_int, c_int,
                              c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                              c_size_t, c_void_p]),
     "lcf_rulebook_subm_workspace_bytes": (c_size_t, [c_int]),
+    "lcf_rulebook_subm_workspace_reset": (c_int, [c_void_p, c_size_t, c_int, c_void_p]),
     "lcf_rulebook_subm": (c_int, [c_void_p, c_int, c_void_p, c_int, _PI3, _PI3, _PI3, c_void_p,
                                   c_void_p, c_size_t, c_void_p]),
     "lcf_rulebook_conv_max_out": (c_int, [c_int, _PI3, _PI3]),
     "lcf_conv_out_shape": (None, [_PI3, _PI3, _PI3, _PI3, _PI3, _PI3]),
     "lcf_rulebook_conv_workspace_bytes": (c_size_t, [c_int, _PI3, _PI3]),
+    "lcf_rulebook_conv_workspace_reset": (c_int, [c_void_p, c_size_t, c_int, _PI3, _PI3,
+                                                  c_void_p]),
     "lcf_rulebook_conv_discover": (c_int, [c_void_p, c_int, c_void_p, c_int, _PI3, _PI3, _PI3,
                                            _PI3, _PI3, c_void_p, c_int, c_void_p, c_void_p,
                                            c_void_p, c_size_t, c_void_p]),
@@ -68,6 +72,7 @@ SYMBOLS = {
 
 # lcf_set_option keys (include/lcf.h)
 OPT_CONV_SPLIT, OPT_CONV_IMPL, OPT_CONV_TILE, OPT_CONV_SETS, OPT_CONV_ROWS_HINT = 0, 1, 2, 3, 4
+OPT_WS_CLEAN = 5
 
 _lib = None
 

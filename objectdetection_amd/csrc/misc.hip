@@ -32,6 +32,8 @@ __global__ void __launch_bounds__(256) lcf_fill32_kernel(uint32_t *p, uint32_t v
     if (t < n32 - tail0) p[tail0 + t] = v;
 }
 
+int g_lcf_ws_clean = 0;
+
 int lcf_fill32(void *p, uint32_t v, size_t bytes, hipStream_t st)
 {
     if (bytes == 0) return LCF_OK;

@@ -389,7 +389,8 @@ extern "C" int lcf_rulebook_subm(const int *coors, int k, const int *k_dev, int 
     uint32_t *keys = (uint32_t *)ws;
     int *vals = (int *)((char *)ws + lcf_align_up((size_t)hc * 4, 256));
     hipStream_t st = (hipStream_t)stream;
-    if (lcf_fill32(keys, 0xFFFFFFFFu, (size_t)hc * 4, st) != LCF_OK) return LCF_ERR_LAUNCH;
+    if (!g_lcf_ws_clean && lcf_fill32(keys, 0xFFFFFFFFu, (size_t)hc * 4, st) != LCF_OK)
+        return LCF_ERR_LAUNCH;
     rb_subm_insert_kernel<<<(k + RB_BLOCK - 1) / RB_BLOCK, RB_BLOCK, 0, st>>>(
         coors, k, k_dev, batch, g, keys, hc - 1, vals);
     LCF_CHECK_LAUNCH();
@@ -398,6 +399,13 @@ extern "C" int lcf_rulebook_subm(const int *coors, int k, const int *k_dev, int 
         coors, k, k_dev, batch, g, keys, hc - 1, vals, out_nbr);
     LCF_CHECK_LAUNCH();
     return LCF_OK;
+}
+
+extern "C" int lcf_rulebook_subm_workspace_reset(void *ws, size_t ws_bytes, int k, void *stream)
+{
+    if (!ws || k < 0) return LCF_ERR_ARG;
+    if (ws_bytes < lcf_rulebook_subm_workspace_bytes(k)) return LCF_ERR_WORKSPACE;
+    return lcf_fill32(ws, 0xFFFFFFFFu, (size_t)rb_capacity(k) * 4, (hipStream_t)stream);
 }
 
 extern "C" int lcf_rulebook_mirror(const int *nbr, int k, int kvol, int *mirrored, void *stream)
@@ -461,6 +469,21 @@ extern "C" size_t lcf_rulebook_conv_workspace_bytes(int k_in, const int ksize[3]
     return rb_conv_carve(nullptr, k_in, (int)e).bytes;
 }
 
+extern "C" int lcf_rulebook_conv_workspace_reset(void *ws, size_t ws_bytes, int k_in,
+                                                 const int ksize[3], const int stride[3],
+                                                 void *stream)
+{
+    if (!ws || k_in < 0 || !ksize || !stride) return LCF_ERR_ARG;
+    long long e = 1;
+    for (int d = 0; d < 3; ++d) {
+        if (ksize[d] <= 0 || stride[d] <= 0) return LCF_ERR_ARG;
+        e *= (ksize[d] + stride[d] - 1) / stride[d];
+    }
+    ConvWs w = rb_conv_carve(ws, k_in, (int)e);
+    if (ws_bytes < w.bytes) return LCF_ERR_WORKSPACE;
+    return lcf_fill32(w.tab, 0xFFFFFFFFu, (size_t)w.hc * 8, (hipStream_t)stream);
+}
+
 extern "C" int lcf_rulebook_conv_discover(const int *coors, int k_in, const int *k_in_dev,
                                           int batch, const int shape[3], const int ksize[3],
                                           const int stride[3], const int pad[3],
@@ -483,7 +506,8 @@ extern "C" int lcf_rulebook_conv_discover(const int *coors, int k_in, const int 
         if (lcf_fill32(k_out, 0u, 4, st) != LCF_OK) return LCF_ERR_LAUNCH;
         return LCF_OK;
     }
-    if (lcf_fill32(w.tab, 0xFFFFFFFFu, (size_t)w.hc * 8, st) != LCF_OK) return LCF_ERR_LAUNCH;
+    if (!g_lcf_ws_clean && lcf_fill32(w.tab, 0xFFFFFFFFu, (size_t)w.hc * 8, st) != LCF_OK)
+        return LCF_ERR_LAUNCH;
     unsigned nb = (unsigned)((w.total + RB_BLOCK - 1) / RB_BLOCK);
     rb_conv_insert_kernel<<<nb, RB_BLOCK, 0, st>>>(coors, k_in, k_in_dev, batch, g, w.tab,
                                                    w.hc - 1, w.cand_slot);

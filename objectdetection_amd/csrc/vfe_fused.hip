@@ -2,7 +2,14 @@
 // as ONE persistent kernel for the shipped shape: F(+3) <= 8 point features -> VFE(16|32) ->
 // VFE(64|128) -> Linear 128 + BN + ReLU -> masked max over the T points of a voxel.
 //
-// A workgroup (4 waves) walks groups of 16 voxels = 16*T point rows.  The three weight matrices
+// A workgroup (4 waves) walks groups of 16 voxels = 16*T point rows, ordered point-major
+// (row = t*16 + voxel) so that a 16-row MFMA tile holds point t of the 16 voxels: tiles with
+// t >= the largest point count of the group are pure padding and are SKIPPED (a 20k-point frame
+// on the 0.05 m grid has 1.14 points per voxel: ~2.2 of 5 tiles remain).  What padding rows
+// contribute in the reference is kept: VFE1 sees them unmasked as (0, -mean) rows, identical
+// within a voxel, so stage 1 runs one tile further (one padding row per voxel); VFE2 sees them
+// masked to zero, so their relu(bn(0)) = relu(shift) is where its maxima start; the last max is
+// masked.  The result is unchanged.  The three weight matrices
 // never touch LDS: each wave keeps the fragments of ITS output columns in registers for the whole
 // kernel (W3: 2 column tiles x 32 k = 64 VGPRs, W2: 8, W1: 2), loaded once from the MFMA weight
 // images (same image layout as the sparse conv, conv.hip).  Activations of the group live in LDS
@@ -98,7 +105,6 @@ vfe_fused_kernel(const float *__restrict__ voxels, const int *__restrict__ num, 
     const int ngroups = (k + VF_V - 1) / VF_V;
     if ((int)blockIdx.x >= ngroups) return;
     const int R = VF_V * T;   // rows per group (multiple of 16)
-    const int NRT = T;        // 16-row tiles per group
 
     extern __shared__ __align__(16) unsigned char smem[];
     float *X0 = reinterpret_cast<float *>(smem);     // [R][VF_S0]
@@ -108,7 +114,6 @@ vfe_fused_kernel(const float *__restrict__ voxels, const int *__restrict__ num, 
     int *P2 = P1 + VF_V * VF_U1;                     // [16][64]
     int *P3 = P2 + VF_V * VF_U2;                     // [16][128]
     int *nv = P3 + VF_V * VF_U3;                     // [16] points per voxel
-    unsigned short *rv = reinterpret_cast<unsigned short *>(nv + VF_V); // [R] voxel | t << 8
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -130,37 +135,51 @@ vfe_fused_kernel(const float *__restrict__ voxels, const int *__restrict__ num, 
         s3[c] = sc3 ? sc3[(2 * wave + c) * 16 + r16] : 1.f;
         h3[c] = sh3 ? sh3[(2 * wave + c) * 16 + r16] : 0.f;
     }
-    for (int r = tid; r < R; r += VF_THREADS) rv[r] = (unsigned short)((r / T) | ((r % T) << 8));
 
     for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
         const int v0 = grp * VF_V;
-        __syncthreads(); // previous group's LDS reads are done (and rv is visible)
-        // ---- stage 0a: rows -> X0[:, 0:F] (zero for voxels past k), maxima = 0
-        for (int r = tid; r < R; r += VF_THREADS) {
-            const int v = v0 + (rv[r] & 255);
+        __syncthreads(); // previous group's LDS reads are done
+        if (tid < VF_V) nv[tid] = (v0 + tid < k) ? num[v0 + tid] : 0;
+        __syncthreads();
+        int tmax = 0; // row tiles that hold a real point
+#pragma unroll
+        for (int i = 0; i < VF_V; ++i) tmax = nv[i] > tmax ? nv[i] : tmax;
+        tmax = tmax < T ? tmax : T;
+        const int Rc = tmax * 16;
+        const int t1 = tmax < T ? tmax + 1 : T; // stage 1 also needs one all-padding tile
+        const int R1 = t1 * 16;
+        // ---- stage 0a: rows -> X0[:, 0:F] (zero for voxels past k); maxima of stage 2 start
+        //      from what the skipped all-padding rows would contribute there: relu(shift)
+        for (int r = tid; r < R1; r += VF_THREADS) {
+            const int v = v0 + (r & 15), t = r >> 4;
             float *d = X0 + r * VF_S0;
-            const float *src = voxels + ((size_t)v0 * T + r) * F;
+            const float *src = voxels + ((size_t)v * T + t) * F;
             for (int e = 0; e < 8; ++e) d[e] = (v < k && e < F) ? src[e] : 0.f;
         }
-        if (tid < VF_V) nv[tid] = (v0 + tid < k) ? num[v0 + tid] : 0;
-        for (int e = tid; e < VF_V * (VF_U1 + VF_U2 + VF_U3); e += VF_THREADS) P1[e] = 0;
+        {
+            const bool skip = tmax < T;
+            for (int e = tid; e < VF_V * VF_U1; e += VF_THREADS) P1[e] = 0;
+            for (int e = tid; e < VF_V * VF_U2; e += VF_THREADS)
+                P2[e] = skip && sh2 ? __float_as_int(fmaxf(sh2[e % VF_U2], 0.f)) : 0;
+            for (int e = tid; e < VF_V * VF_U3; e += VF_THREADS) P3[e] = 0;
+        }
         __syncthreads();
-        // ---- stage 0b: centre xyz on the voxel mean: X0[:, F:F+3]
-        for (int r = tid; r < R; r += VF_THREADS) {
-            const int vl = rv[r] & 255;
+        // ---- stage 0b: centre xyz on the voxel mean: X0[:, F:F+3] (rows past tmax are zeros)
+        for (int r = tid; r < R1; r += VF_THREADS) {
+            const int vl = r & 15;
             const float n = (float)(nv[vl] > 0 ? nv[vl] : 1); // voxels past k: keep it finite
-            const float *base = X0 + vl * T * VF_S0;
+            const float *base = X0 + vl * VF_S0;
             float *d = X0 + r * VF_S0;
 #pragma unroll
             for (int e = 0; e < 3; ++e) {
                 float s = 0.f;
-                for (int i = 0; i < T; ++i) s += base[i * VF_S0 + e];
+                for (int i = 0; i < tmax; ++i) s += base[i * 16 * VF_S0 + e];
                 d[F + e] = d[e] - __fdiv_rn(s, n);
             }
         }
         __syncthreads();
         // ---- stage 1: [R,8] x W1[8,16]; row tiles round-robin over the waves
-        for (int rt = wave; rt < NRT; rt += 4) {
+        for (int rt = wave; rt < t1; rt += 4) {
             float a[2];
             vf_aload<2>(X0 + (rt * 16 + r16) * VF_S0 + q * 2, a);
             f32x4 acc = vf_dot<2>(a, b1);
@@ -169,20 +188,20 @@ vfe_fused_kernel(const float *__restrict__ voxels, const int *__restrict__ num, 
                 const int row = rt * 16 + q * 4 + r;
                 const float y = fmaxf(acc[r] * s1 + h1, 0.f);
                 X1[row * VF_S1 + r16] = y;
-                atomicMax(&P1[(rv[row] & 255) * VF_U1 + r16], __float_as_int(y));
+                atomicMax(&P1[(q * 4 + r) * VF_U1 + r16], __float_as_int(y));
             }
         }
         __syncthreads();
-        for (int e = tid; e < R * VF_U1; e += VF_THREADS) {
+        for (int e = tid; e < Rc * VF_U1; e += VF_THREADS) {
             const int row = e / VF_U1, c = e % VF_U1;
-            const int vl = rv[row] & 255, t = rv[row] >> 8;
+            const int vl = row & 15, t = row >> 4;
             const float m = t < nv[vl] ? 1.f : 0.f;
             X1[row * VF_S1 + c] *= m;
             X1[row * VF_S1 + VF_U1 + c] = __int_as_float(P1[vl * VF_U1 + c]) * m;
         }
         __syncthreads();
         // ---- stage 2: [R,32] x W2[32,64]; wave = column tile
-        for (int rt = 0; rt < NRT; ++rt) {
+        for (int rt = 0; rt < tmax; ++rt) {
             float a[8];
             vf_aload<8>(X1 + (rt * 16 + r16) * VF_S1 + q * 8, a);
             f32x4 acc = vf_dot<8>(a, b2);
@@ -191,20 +210,20 @@ vfe_fused_kernel(const float *__restrict__ voxels, const int *__restrict__ num, 
                 const int row = rt * 16 + q * 4 + r;
                 const float y = fmaxf(acc[r] * s2 + h2, 0.f);
                 X2[row * VF_S2 + wave * 16 + r16] = y;
-                atomicMax(&P2[(rv[row] & 255) * VF_U2 + wave * 16 + r16], __float_as_int(y));
+                atomicMax(&P2[(q * 4 + r) * VF_U2 + wave * 16 + r16], __float_as_int(y));
             }
         }
         __syncthreads();
-        for (int e = tid; e < R * VF_U2; e += VF_THREADS) {
+        for (int e = tid; e < Rc * VF_U2; e += VF_THREADS) {
             const int row = e / VF_U2, c = e % VF_U2;
-            const int vl = rv[row] & 255, t = rv[row] >> 8;
+            const int vl = row & 15, t = row >> 4;
             const float m = t < nv[vl] ? 1.f : 0.f;
             X2[row * VF_S2 + c] *= m;
             X2[row * VF_S2 + VF_U2 + c] = __int_as_float(P2[vl * VF_U2 + c]) * m;
         }
         __syncthreads();
         // ---- stage 3: [R,128] x W3[128,128]; wave = 2 column tiles; masked max over T
-        for (int rt = 0; rt < NRT; ++rt) {
+        for (int rt = 0; rt < tmax; ++rt) {
             float a[32];
             vf_aload<32>(X2 + (rt * 16 + r16) * VF_S2 + q * 32, a);
 #pragma unroll
@@ -212,10 +231,9 @@ vfe_fused_kernel(const float *__restrict__ voxels, const int *__restrict__ num, 
                 f32x4 acc = vf_dot<32>(a, b3[c]);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int row = rt * 16 + q * 4 + r;
-                    const int vl = rv[row] & 255, t = rv[row] >> 8;
+                    const int vl = q * 4 + r;
                     float y = fmaxf(acc[r] * s3[c] + h3[c], 0.f);
-                    y = t < nv[vl] ? y : 0.f;
+                    y = rt < nv[vl] ? y : 0.f;
                     atomicMax(&P3[vl * VF_U3 + (2 * wave + c) * 16 + r16], __float_as_int(y));
                 }
             }
@@ -234,7 +252,7 @@ static size_t vf_lds_bytes(int T)
 {
     size_t R = (size_t)VF_V * T;
     size_t b = R * (VF_S0 + VF_S1 + VF_S2) * 4;
-    b += (size_t)VF_V * (VF_U1 + VF_U2 + VF_U3) * 4 + VF_V * 4 + R * 2 + 16;
+    b += (size_t)VF_V * (VF_U1 + VF_U2 + VF_U3) * 4 + VF_V * 4 + 16;
     return b;
 }
 

@@ -223,6 +223,23 @@ extern "C" size_t lcf_voxelize_workspace_bytes(int n, int max_pts)
     return vox_carve(nullptr, n, max_pts).bytes;
 }
 
+static int vox_reset(const VoxWs &w, int max_pts, hipStream_t st)
+{
+    if (lcf_fill32(w.keys, 0xFFFFFFFFu, (size_t)w.hc * 4, st) != LCF_OK) return LCF_ERR_LAUNCH;
+    if (lcf_fill32(w.lists, (uint32_t)VOX_SENT, (size_t)w.hc * max_pts * 4, st) != LCF_OK)
+        return LCF_ERR_LAUNCH;
+    return LCF_OK;
+}
+
+extern "C" int lcf_voxelize_workspace_reset(void *ws, size_t ws_bytes, int n, int max_pts,
+                                            void *stream)
+{
+    if (!ws || n < 0 || max_pts <= 0) return LCF_ERR_ARG;
+    VoxWs w = vox_carve(ws, n, max_pts);
+    if (ws_bytes < w.bytes) return LCF_ERR_WORKSPACE;
+    return vox_reset(w, max_pts, (hipStream_t)stream);
+}
+
 extern "C" int lcf_voxelize(const float *points, int n, const int *n_dev, int f,
                             const float vs[3], const float range[6], int max_pts, int max_vox,
                             int cap_mode, int batch_idx, int coor_stride, float *voxels,
@@ -249,9 +266,7 @@ extern "C" int lcf_voxelize(const float *points, int n, const int *n_dev, int f,
     VoxWs w = vox_carve(ws, n, max_pts);
     if (ws_bytes < w.bytes) return LCF_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
-    if (lcf_fill32(w.keys, 0xFFFFFFFFu, (size_t)w.hc * 4, st) != LCF_OK) return LCF_ERR_LAUNCH;
-    if (lcf_fill32(w.lists, (uint32_t)VOX_SENT, (size_t)w.hc * max_pts * 4, st) != LCF_OK)
-        return LCF_ERR_LAUNCH;
+    if (!g_lcf_ws_clean && vox_reset(w, max_pts, st) != LCF_OK) return LCF_ERR_LAUNCH;
     if (n > 0) {
         vox_insert_kernel<<<(n + VOX_BLOCK - 1) / VOX_BLOCK, VOX_BLOCK, 0, st>>>(
             points, n, n_dev, f, p, max_pts, w.keys, w.hc - 1, w.lists, w.cellslot);

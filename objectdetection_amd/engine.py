@@ -21,6 +21,8 @@ Capacities of the strided levels are calibrated on sample frames (x ``margin``);
 exceeds them sets a device flag, reported by ``check()`` (``forward(..., sync=True)`` re-plans
 with larger capacities and re-runs the frame on its own).
 """
+import os
+
 import torch
 from torch import nn
 
@@ -232,6 +234,29 @@ class FrameEngine:
         self.dense = E(1, C, D, H, W)
         self.out = self.dense.view(1, C * D, H, W)
         self.graph = None
+        self._reset_workspaces(torch.cuda.current_stream(dev).cuda_stream)
+
+    def _reset_workspaces(self, st):
+        """Hash workspaces of the voxelizer and of every rulebook into their reset state.  A frame
+        runs with LCF_OPT_WS_CLEAN (the calls skip their own resets) and re-arms the workspaces
+        at the END of its rulebook branch, where the fills overlap the convolutions instead of
+        sitting in front of the voxelizer and of every rulebook."""
+        L = self.L
+        check(L.lcf_voxelize_workspace_reset(self.vox_ws.data_ptr(), self.vox_ws.numel(),
+                                             self.max_points, self.T, st))
+        done = set()
+        for l in self.layers:
+            o = l.rb_owner
+            if id(o) in done:
+                continue
+            done.add(id(o))
+            if o.subm:
+                check(L.lcf_rulebook_subm_workspace_reset(o.ws.data_ptr(), o.ws.numel(),
+                                                          o.k_in_cap, st))
+            else:
+                check(L.lcf_rulebook_conv_workspace_reset(o.ws.data_ptr(), o.ws.numel(),
+                                                          o.k_in_cap, i3(o.ksize), i3(o.stride),
+                                                          st))
 
     # ------------------------------------------------------------------ one frame, enqueued
     def _enqueue(self):
@@ -241,12 +266,26 @@ class FrameEngine:
         which fill the chip).  Captured into a hipGraph the cross-stream events become edges of
         the graph: two branches that join at each conv."""
         L = self.L
+        L.lcf_set_option(_lib.OPT_WS_CLEAN, int(os.environ.get("LCF_ENGINE_WS_CLEAN", "1")))
+        try:
+            self._enqueue_clean()
+        finally:
+            L.lcf_set_option(_lib.OPT_WS_CLEAN, 0)
+            L.lcf_set_option(_lib.OPT_CONV_ROWS_HINT, 0)
+
+    def _enqueue_clean(self):
+        L = self.L
         main = torch.cuda.current_stream(self.dev)
         side = self.side if self.two_streams else main
         st, sst = main.cuda_stream, side.cuda_stream
         P = lambda t: None if t is None else t.data_ptr()
         MV, T, F = self.max_voxels, self.T, self.F
-        self.flags.zero_()
+        if self.two_streams:  # overflow flags: only the rulebook branch writes them
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                self.flags.zero_()
+        else:
+            self.flags.zero_()
         check(L.lcf_voxelize(P(self.points), self.max_points, P(self.n_dev), F, f3(self.vs),
                              f6(self.rng), T, MV, self.cap_mode, 0, 4, P(self.voxels),
                              P(self.coors), P(self.num), P(self.vnum), P(self.vox_ws),
@@ -287,6 +326,10 @@ class FrameEngine:
             if self.two_streams:
                 e_dense = torch.cuda.Event()
                 e_dense.record(side)
+            self._reset_workspaces(sst)  # for the next frame
+            if self.two_streams:
+                e_side = torch.cuda.Event()
+                e_side.record(side)
         # ---- main stream: features
         if self.vfe_kind == "vfe" and self.vfe_fused:
             (w1, c0, u1, s1, h1), (w2, _, u2, s2, h2), (w3, _, u3, s3, h3) = self.lin
@@ -332,9 +375,11 @@ class FrameEngine:
                 coors, kd = l.out_coors, l.k_out
         L.lcf_set_option(_lib.OPT_CONV_ROWS_HINT, 0)
         if self.two_streams:
-            main.wait_event(e_dense)  # also joins the side stream (its last operation)
+            main.wait_event(e_dense)
         check(L.lcf_dense(P(feat), P(coors), feat.shape[0], P(kd), feat.shape[1], 1,
                           i3(self.out_shape), 0, P(self.dense), st))
+        if self.two_streams:
+            main.wait_event(e_side)  # joins the side stream (its last operation)
 
     def _capture(self):
         s = torch.cuda.Stream(device=self.dev)

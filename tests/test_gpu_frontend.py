@@ -155,8 +155,12 @@ def test_vfe_fused_kernel_matches_layer_kernels(cuda):
     from objectdetection_amd import ops, voxel_encoder as ve
     torch.manual_seed(5)
     m = randomize_(ve.VoxelFeatureExtractor(4, True, [32, 128]).eval(), 7).to(cuda)
-    for k, t in [(1, 5), (17, 5), (5003, 5), (333, 8), (40, 1)]:
+    for k, t, sparse in [(1, 5, False), (17, 5, False), (5003, 5, False), (333, 8, False),
+                         (40, 1, False), (6001, 5, True), (2000, 8, True)]:
         num = torch.randint(1, t + 1, (k,), dtype=torch.int32, device=cuda)
+        if sparse:  # mostly one point per voxel: the kernel skips the all-padding row tiles
+            few = torch.rand(k, device=cuda) < 0.9
+            num = torch.where(few, torch.ones_like(num), num)
         vox = torch.randn(k, t, 4, device=cuda)
         vox = vox * (torch.arange(t, device=cuda)[None, :, None] < num[:, None, None])
         with torch.no_grad():
@@ -169,7 +173,7 @@ def test_vfe_fused_kernel_matches_layer_kernels(cuda):
             x = m.linear(x)
             sc, sh = ve._affine(m.norm, 128, x.device)
             layered = ops.vfe_pool(x, num, sc, sh, 1)
-        assert rel_err(fused.cpu().numpy(), layered.cpu().numpy()) < 1e-5, (k, t)
+        assert rel_err(fused.cpu().numpy(), layered.cpu().numpy()) < 1e-5, (k, t, sparse)
         # device-side count: only the first kd voxels are written
         kd = max(1, k // 2)
         out = torch.full((k, 128), -1.0, device=cuda)
