@@ -132,6 +132,51 @@ def test_dense_matches_oracle(oracle, cuda):
     assert torch.equal(xt.grad, ref_g)
 
 
+@pytest.mark.parametrize("cin,cout", [(32, 32), (64, 64), (32, 64), (20, 40), (128, 128)])
+@pytest.mark.parametrize("sets,tile", [(1, 32), (2, 32), (1, 17), (2, 25), (2, 16)])
+def test_tile_compacted_variants_match_oracle(oracle, cuda, cin, cout, sets, tile):
+    """Every launch-time variant of the tile-compacted forward (one / two wave sets, tile heights
+    16..32) against the oracle, pinned with lcf_set_option; two sets are run-to-run deterministic."""
+    from objectdetection_amd import _lib
+    rng = np.random.default_rng(cin + 7 * cout + sets + tile)
+    coors = _frame_coors(oracle, 3, 7000)
+    extra = coors.copy()
+    extra[:, 2] = np.minimum(extra[:, 2] + 1, 1599)
+    coors = np.ascontiguousarray(np.unique(np.concatenate([coors, extra], 0), axis=0))
+    shape = [41, 1600, 1408]
+    k = coors.shape[0]
+    x = rng.standard_normal((k, cin)).astype(np.float32)
+    w = (rng.standard_normal((3, 3, 3, cin, cout)) / np.sqrt(27 * cin)).astype(np.float32)
+    pairs, pn = oracle.rulebook_subm(coors, 1, shape, 3)
+    ref = oracle.indice_conv_fwd(x, w, pairs, pn, k)
+    rb = ops.build_rulebook(torch.from_numpy(coors).to(cuda), 1, shape, 3, 1, 1, 1, True)
+    xt, wt = torch.from_numpy(x).to(cuda), torch.from_numpy(w).to(cuda)
+    L = _lib.lib()
+    try:
+        assert L.lcf_set_option(_lib.OPT_CONV_IMPL, 2) == 0
+        assert L.lcf_set_option(_lib.OPT_CONV_SETS, sets) == 0
+        assert L.lcf_set_option(_lib.OPT_CONV_TILE, tile) == 0
+        out = ops.conv_forward(xt, ops.weight_image(wt), rb.out_nbr, rb.k_out, 27, cin, cout)
+        again = ops.conv_forward(xt, ops.weight_image(wt), rb.out_nbr, rb.k_out, 27, cin, cout)
+    finally:
+        L.lcf_set_option(_lib.OPT_CONV_IMPL, 0)
+        L.lcf_set_option(_lib.OPT_CONV_SETS, 0)
+        L.lcf_set_option(_lib.OPT_CONV_TILE, 0)
+    assert rel_err(out.cpu().numpy(), ref) < RTOL
+    assert torch.equal(out, again)
+
+
+def test_option_values_are_validated(cuda):
+    from objectdetection_amd import _lib
+    L = _lib.lib()
+    assert L.lcf_set_option(_lib.OPT_CONV_TILE, 15) != 0
+    assert L.lcf_set_option(_lib.OPT_CONV_TILE, 33) != 0
+    assert L.lcf_set_option(_lib.OPT_CONV_SETS, 3) != 0
+    assert L.lcf_set_option(_lib.OPT_CONV_IMPL, 4) != 0
+    assert L.lcf_set_option(_lib.OPT_WS_CLEAN, 2) != 0
+    assert L.lcf_set_option(99, 0) != 0
+
+
 BF16_RTOL = 2e-2  # stated bf16 tolerance (north star): bf16 operands, fp32 accumulation
 
 
