@@ -46,6 +46,13 @@ class FlatGradAllReduce:
     def zero(self):
         self.flat.zero_()
 
+    def clip_norm_(self, max_norm):
+        """torch.nn.utils.clip_grad_norm_ over all parameters, on the flat buffer: the 2-norm of
+        the concatenation is the norm of the per-tensor norms.  Returns the total norm."""
+        total = torch.linalg.vector_norm(self.flat)
+        self.flat.mul_(torch.clamp(max_norm / (total + 1e-6), max=1.0))
+        return total
+
     def reduce(self, async_op=False):
         """Average gradients over ranks (sum, then divide by world size)."""
         if not (dist.is_available() and dist.is_initialized()):

@@ -81,6 +81,6 @@ class TrainStep:
             loss = synthetic_loss(self.net(clouds), self.gen)
             loss.backward()
         self.bucket.reduce()
-        torch.nn.utils.clip_grad_norm_(self.net.parameters(), 10.0)  # train.py:342
+        self.bucket.clip_norm_(10.0)  # clip_grad_norm_(parameters, 10.0), train.py:342
         self.opt.step()
         return loss.detach()

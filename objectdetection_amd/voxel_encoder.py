@@ -87,6 +87,25 @@ def _fast_path(module, *tensors):
             and all(t.is_cuda and t.dtype == torch.float32 for t in tensors))
 
 
+class _SegmentMax(torch.autograd.Function):
+    """out[k] = max(init[k], max over rows r with seg[r] == k of y[r]); the gradient goes to every
+    element that attains the maximum (torch.max(dim) picks one of them and scatter_reduce splits
+    it evenly; ties only occur at relu's zero, where the gradient is dropped anyway)."""
+
+    @staticmethod
+    def forward(ctx, init, seg, y):
+        idx = seg.unsqueeze(1).expand(-1, y.shape[1])
+        out = init.scatter_reduce(0, idx, y, "amax", include_self=True)
+        ctx.save_for_backward(init, seg, y, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        init, seg, y, out = ctx.saved_tensors
+        gy = g[seg] * (y == out[seg])
+        return g * (init == out), None, gy
+
+
 class VFELayer(nn.Module):
     def __init__(self, in_channels, out_channels, use_norm=True, name='vfe'):
         super().__init__()
@@ -122,6 +141,82 @@ class _VFEBase(nn.Module):
             points_dist = torch.norm(features[:, :, :3], 2, 2, keepdim=True)
             return torch.cat([features, features_relative, points_dist], dim=-1)
         return torch.cat([features, features_relative], dim=-1)
+
+    compact_training = True  # training forward over the real points only (_forward_compact)
+
+    @staticmethod
+    def _bn_rows(norm, xr, n, xp=None, wp=None):
+        """BatchNorm1d over n rows of which only a part is materialised: the rows xr once, plus
+        either the rows xp with multiplicities wp, or (xp None) n - len(xr) rows of zeros.
+        Returns the per-channel (scale, shift) of the normalisation, differentiable through the
+        batch statistics, and updates the running statistics as nn.BatchNorm1d does."""
+        if norm.training or not norm.track_running_stats:
+            if xp is not None:
+                w = wp.unsqueeze(1)
+                mean = (xr.sum(0) + (w * xp).sum(0)) / n
+                var = (((xr - mean) ** 2).sum(0) + (w * (xp - mean) ** 2).sum(0)) / n
+            else:
+                mean = xr.sum(0) / n
+                var = (((xr - mean) ** 2).sum(0) + (n - xr.shape[0]) * mean ** 2) / n
+            if norm.training and norm.track_running_stats:
+                with torch.no_grad():
+                    norm.num_batches_tracked += 1
+                    m = norm.momentum
+                    if m is None:
+                        m = 1.0 / float(norm.num_batches_tracked)
+                    norm.running_mean.mul_(1 - m).add_(mean.detach(), alpha=m)
+                    norm.running_var.mul_(1 - m).add_(var.detach() * (n / max(n - 1, 1)), alpha=m)
+        else:
+            mean, var = norm.running_mean, norm.running_var
+        scale = torch.rsqrt(var + norm.eps)
+        if norm.weight is not None:
+            scale = scale * norm.weight
+        shift = -mean * scale
+        if norm.bias is not None:
+            shift = shift + norm.bias
+        return scale, shift
+
+    def _forward_compact(self, layers, features, num_voxels):
+        """Training forward of voxel_encoder.py:113-140 over the REAL points only.  A 20k-point
+        frame fills 1.14 of the T = 5 slots of a voxel, so the reference's [K, T, C] tensors are
+        78 % padding; here every layer runs on the P real rows (plus one padding representative
+        per voxel where the reference feeds padding rows unmasked), and what the padding rows
+        contribute to the batch statistics and to the per-voxel max is added in closed form:
+          * first layer: padding rows of a voxel are identical, (0, -mean) -> Linear -> BN -> ReLU:
+            one row per voxel with multiplicity T - num in the statistics, once in the max;
+          * later layers and the final Linear see padding rows masked to zero: Linear (no bias)
+            gives zeros, so they add n - P zeros to the statistics and relu(shift) to the max.
+        Same values as the dense form up to fp32 summation order; same running statistics."""
+        k, t = features.shape[0], features.shape[1]
+        n = k * t
+        aug = self._augment(features, num_voxels)
+        mask = get_paddings_indicator(num_voxels, t, axis=0)
+        rows = mask.reshape(-1).nonzero(as_tuple=True)[0]          # flat ids of the real rows
+        vk = torch.div(rows, t, rounding_mode="floor")
+        wp = (t - num_voxels.clamp(max=t)).to(aug.dtype)           # padding rows per voxel
+        has_pad = (wp > 0).unsqueeze(1)
+        xr = aug.reshape(n, -1)[rows]
+        xp = aug[:, t - 1, :]                                      # a padding row where wp > 0
+        neg = torch.finfo(aug.dtype).min
+        for i, vfe in enumerate(layers):
+            yr = vfe.linear(xr)
+            c = yr.shape[1]
+            if i == 0:
+                yp = vfe.linear(xp)
+                scale, shift = self._bn_rows(vfe.norm, yr, n, yp, wp)
+                pad = F.relu(yp * scale + shift)
+            else:
+                scale, shift = self._bn_rows(vfe.norm, yr, n)
+                pad = F.relu(shift).expand(k, c)
+            yr = F.relu(yr * scale + shift)
+            init = torch.where(has_pad, pad, torch.full_like(pad, neg))
+            agg = _SegmentMax.apply(init, vk, yr)
+            xr = torch.cat([yr, agg[vk]], dim=1)
+        yr = self.linear(xr)
+        scale, shift = self._bn_rows(self.norm, yr, n)
+        yr = F.relu(yr * scale + shift)
+        out = torch.zeros((k, yr.shape[1]), dtype=yr.dtype, device=yr.device)
+        return _SegmentMax.apply(out, vk, yr)
 
     def _fused_lin(self, layers):
         """[(weight image, cin, cout, scale, shift)] of the three Linear layers, cached until a
@@ -161,6 +256,10 @@ class _VFEBase(nn.Module):
             x = self.linear(x)
             scale, shift = _affine(self.norm, x.shape[-1], x.device)
             return ops.vfe_pool(x, num_voxels, scale, shift, 1)
+        if (self.training and self.compact_training and features.shape[0] > 0
+                and all(isinstance(l.norm, nn.BatchNorm1d) for l in layers)
+                and isinstance(self.norm, nn.BatchNorm1d)):
+            return self._forward_compact(layers, features, num_voxels)
         features = self._augment(features, num_voxels)
         voxel_count = features.shape[1]
         mask = get_paddings_indicator(num_voxels, voxel_count, axis=0)

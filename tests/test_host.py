@@ -252,3 +252,27 @@ def test_conv_math_switch():
     import pytest
     with pytest.raises(ValueError):
         ops.conv_math("fp8")
+
+
+def test_flat_bucket_clip_equals_clip_grad_norm():
+    """FlatGradAllReduce.clip_norm_ on the flat buffer == torch.nn.utils.clip_grad_norm_ over the
+    parameters (reference train.py:342)."""
+    import copy
+    import torch
+    from objectdetection_amd.dist import FlatGradAllReduce
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.Linear(5, 3))
+    ref = copy.deepcopy(net)
+    bucket = FlatGradAllReduce(net.parameters())
+    x = torch.randn(11, 7)
+    for scale in (100.0, 1e-3):  # clipped / left alone
+        bucket.zero()
+        for p in ref.parameters():
+            p.grad = None
+        (net(x).sum() * scale).backward()
+        (ref(x).sum() * scale).backward()
+        total = bucket.clip_norm_(10.0)
+        total_ref = torch.nn.utils.clip_grad_norm_(ref.parameters(), 10.0)
+        assert torch.allclose(total, total_ref, rtol=1e-6)
+        for p, q in zip(net.parameters(), ref.parameters()):
+            assert torch.allclose(p.grad, q.grad, rtol=1e-5, atol=1e-8)

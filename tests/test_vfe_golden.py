@@ -76,3 +76,38 @@ def test_product_modules_load_reference_state_and_match(tag, kw):
     for k, v in m.state_dict().items():
         if "running" in k:
             assert rel_err(v.numpy(), G[f"{tag}/after/{k}"]) < TOL, k
+
+
+@pytest.mark.parametrize("cls,kw", [("VoxelFeatureExtractor", dict(num_filters=[32, 128])),
+                                    ("VoxelFeatureExtractorV2", dict(num_filters=[16, 32, 64])),
+                                    ("VoxelFeatureExtractor", dict(num_filters=[32, 128],
+                                                                   with_distance=True))])
+def test_compact_training_forward_equals_dense_form(cls, kw):
+    """The training forward over the real points only (_forward_compact: padding rows enter the
+    batch statistics and the per-voxel max in closed form) against the reference's dense
+    [K, T, C] form: outputs, parameter gradients and running statistics."""
+    import copy
+    from objectdetection_amd import voxel_encoder as ve
+    torch.manual_seed(3)
+    k, t = 700, 5
+    num = torch.randint(1, t + 1, (k,), dtype=torch.int32)
+    num[torch.rand(k) < 0.7] = 1                      # mostly one point per voxel, some full
+    vox = torch.randn(k, t, 4) * (torch.arange(t)[None, :, None] < num[:, None, None])
+    a = ve.get_vfe_class(cls)(num_input_features=4, **kw).train()
+    for p in a.parameters():
+        torch.nn.init.normal_(p, std=0.3)
+    for m in a.modules():
+        if isinstance(m, torch.nn.BatchNorm1d):
+            torch.nn.init.uniform_(m.weight, 0.5, 1.5)
+            torch.nn.init.normal_(m.bias, std=0.3)
+    b = copy.deepcopy(a)
+    b.compact_training = False
+    g = torch.randn(k, a.linear.out_features)
+    ya, yb = a(vox, num, None), b(vox, num, None)
+    assert rel_err(ya.detach().numpy(), yb.detach().numpy()) < TOL
+    (ya * g).sum().backward()
+    (yb * g).sum().backward()
+    for (na, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
+        assert rel_err(pa.grad.numpy(), pb.grad.numpy()) < 1e-4, na
+    for (na, ba), (_, bb) in zip(a.named_buffers(), b.named_buffers()):
+        assert rel_err(ba.numpy(), bb.numpy()) < TOL, na
