@@ -614,7 +614,7 @@ cv_tc_kernel(const float *__restrict__ feat, const float *__restrict__ wimg,
 
     const int tidw = threadIdx.x;          // thread of the workgroup
     const int lane = tidw & 63;
-    const int wavew = tidw >> 6;           // wave of the workgroup
+    const int wavew = __builtin_amdgcn_readfirstlane(tidw >> 6); // wave of the workgroup (SGPR)
     const int set = wavew / C::NW;         // wave set (0 when NSETS == 1)
     const int wave = wavew % C::NW;        // = column slice
     const int tid = tidw - set * THREADS;  // thread of the set
@@ -678,10 +678,8 @@ cv_tc_kernel(const float *__restrict__ feat, const float *__restrict__ wimg,
     }
     __syncthreads();
     for (int e = tidw; e < NSETS * OTE; e += TT) ot0[e] = 0.f; // nl is dead now
-    const int n_steps = *nsteps_p;
+    const int n_steps = __builtin_amdgcn_readfirstlane(*nsteps_p);
     __syncthreads();
-
-    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
 
     struct AReg { float4 v[MAXG][APT]; };
     struct BReg {
@@ -697,8 +695,7 @@ cv_tc_kernel(const float *__restrict__ feat, const float *__restrict__ wimg,
 #pragma unroll
             for (int x = 0; x < APT; ++x) {
                 const int ch = tid + x * THREADS;
-                a.v[g][x] = zero4;
-                if (g < ng && (AFULL || ch < ACH)) {
+                if (g < ng && (AFULL || ch < ACH)) { // astore reads a.v[g][x] under the same test
                     const int r = ch / CH, cc = ch % CH;
                     const unsigned e = ent[(i0 + g) * 16 + r];
                     const float *src = feat + (size_t)(e >> 7) * cin + cc * 4;
@@ -847,26 +844,30 @@ cv_tc_kernel(const float *__restrict__ feat, const float *__restrict__ wimg,
     };
 
     if (n_steps > 0) {
-        // set j walks steps j, j + NSETS, ...; the workgroup walks them in lockstep rounds
+        // set j walks steps j, j + NSETS, ...; the workgroup walks them in lockstep rounds.
+        // Step metadata is wave-uniform: kept in SGPRs so that the tests below are scalar
+        // branches, not exec-mask updates (fp32 MFMAs and VALU work do not overlap on a SIMD,
+        // see DESIGN.md: every VALU instruction of this loop is paid in full).
         const int n_rounds = (n_steps + NSETS - 1) / NSETS;
         int s = set;
-        int o = soff[s < n_steps ? s : 0];
-        int i0 = gbase[o], ng = s < n_steps ? (cnt[o] + 15) >> 4 : 0;
-        BReg bcur = bload(o);
+        int o = __builtin_amdgcn_readfirstlane(soff[s < n_steps ? s : 0]);
+        int i0 = __builtin_amdgcn_readfirstlane(gbase[o]);
+        int ng = s < n_steps ? __builtin_amdgcn_readfirstlane((cnt[o] + 15) >> 4) : 0;
+        BReg b0 = bload(o), b1;
         {
             AReg a0 = agather(i0, ng);
             astore(0, a0, ng);
         }
         __syncthreads();
-        for (int u = 0; u < n_rounds; ++u, s += NSETS) {
+        // one round: compute step s from bcur while step s + NSETS loads into bnext
+        auto round = [&](int u, const BReg &bcur, BReg &bnext) {
             const bool more = s + NSETS < n_steps; // uniform over the set
-            BReg bnext = bcur;
             AReg an;
             int on = o, i0n = i0, ngn = 0;
             if (more) {
-                on = soff[s + NSETS];
-                i0n = gbase[on];
-                ngn = (cnt[on] + 15) >> 4;
+                on = __builtin_amdgcn_readfirstlane(soff[s + NSETS]);
+                i0n = __builtin_amdgcn_readfirstlane(gbase[on]);
+                ngn = __builtin_amdgcn_readfirstlane((cnt[on] + 15) >> 4);
                 bnext = bload(on);
                 an = agather(i0n, ngn);
             }
@@ -877,10 +878,14 @@ cv_tc_kernel(const float *__restrict__ feat, const float *__restrict__ wimg,
             if constexpr (ABUFS == 1) __syncthreads(); // single buffer: everyone done reading
             if (more) astore(ABUFS == 2 ? ((u + 1) & 1) : 0, an, ngn);
             __syncthreads();
-            bcur = bnext;
             o = on;
             i0 = i0n;
             ng = ngn;
+            s += NSETS;
+        };
+        for (int u = 0; u < n_rounds; u += 2) { // W fragments alternate between b0 and b1
+            round(u, b0, b1);
+            if (u + 1 < n_rounds) round(u + 1, b1, b0);
         }
     }
 
