@@ -807,26 +807,25 @@ cv_tc_kernel(const float *__restrict__ feat, const float *__restrict__ wimg,
         const uint4 e4 = *reinterpret_cast<const uint4 *>(ent + i * 16 + q * 4);
         const int orow[4] = {(int)(e4.x & 127u), (int)(e4.y & 127u), (int)(e4.z & 127u),
                              (int)(e4.w & 127u)};
-        f32x4 acc[NT][2];
+        // one accumulator chain per column tile: an MFMA whose C operand is the previous
+        // one's result issues back to back, and a second chain would cost four VALU adds per
+        // group to merge (VALU time is what this kernel is short of)
+        f32x4 acc[NT];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            acc[t][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            acc[t][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        }
+        for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
         if constexpr (BF16) {
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
                 for (int t = 0; t < NT; ++t)
-                    acc[t][ks & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                        ah[ks], w.h[t][ks], acc[t][ks & 1], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[ks], w.h[t][ks], acc[t],
+                                                                     0, 0, 0);
         } else {
 #pragma unroll
             for (int s = 0; s < KL; ++s)
 #pragma unroll
                 for (int t = 0; t < NT; ++t)
-                    acc[t][s & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], w.b[t][s],
-                                                                         acc[t][s & 1], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], w.b[t][s], acc[t], 0, 0, 0);
         }
         // tile[orow][cols of this wave] += group result (col = lane&15); exclusive ownership
         float cur[4][NT];
@@ -839,8 +838,7 @@ cv_tc_kernel(const float *__restrict__ feat, const float *__restrict__ wimg,
         for (int r = 0; r < 4; ++r)
 #pragma unroll
             for (int t = 0; t < NT; ++t)
-                ot[orow[r] * OSTR + wave * NT * 16 + r16 + t * 16] =
-                    cur[r][t] + (acc[t][0][r] + acc[t][1][r]);
+                ot[orow[r] * OSTR + wave * NT * 16 + r16 + t * 16] = cur[r][t] + acc[t][r];
     };
 
     if (n_steps > 0) {
