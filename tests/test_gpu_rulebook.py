@@ -119,3 +119,63 @@ def test_known_answers(cuda):
     assert rb.out_indices.cpu().tolist()[:4] == [[0, 3, 3, 3], [0, 3, 3, 2], [0, 3, 2, 3],
                                                  [0, 3, 2, 2]]
     assert rb.indice_pair_num.sum().item() == 12
+
+
+def test_ws_clean_protocol_matches_default(cuda):
+    """LCF_OPT_WS_CLEAN: with the workspaces put into their reset state by the *_workspace_reset
+    entry points (once before the first call and again after each use), voxelize and both rulebook
+    builders give exactly what the self-resetting default gives, twice in a row on the SAME
+    workspaces; a dirty workspace is the caller's bug, so only the protocol is tested."""
+    import torch
+    from objectdetection_amd import _lib, ops, synth
+    from objectdetection_amd._lib import check, f3, f6, i3
+    L = _lib.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    P = lambda t: t.data_ptr()
+    T, MV = 5, 40000
+    shape, ks, one, zero = [41, 1600, 1408], [3, 3, 3], [1, 1, 1], [0, 0, 0]
+    two = [2, 2, 2]
+    n_max = 20000
+    vws = torch.empty(L.lcf_voxelize_workspace_bytes(n_max, T), dtype=torch.uint8, device=cuda)
+    sws = torch.empty(L.lcf_rulebook_subm_workspace_bytes(MV), dtype=torch.uint8, device=cuda)
+    cws = torch.empty(L.lcf_rulebook_conv_workspace_bytes(MV, i3(ks), i3(two)), dtype=torch.uint8,
+                      device=cuda)
+
+    def reset():
+        check(L.lcf_voxelize_workspace_reset(P(vws), vws.numel(), n_max, T, st))
+        check(L.lcf_rulebook_subm_workspace_reset(P(sws), sws.numel(), MV, st))
+        check(L.lcf_rulebook_conv_workspace_reset(P(cws), cws.numel(), MV, i3(ks), i3(two), st))
+
+    reset()
+    for seed in (0, 1):
+        pts = torch.from_numpy(synth.vkitti_frame(seed, n_max)).to(cuda)
+        ref = ops.voxelize(pts, synth.VOXEL_SIZE, synth.PC_RANGE, T, MV, batch_idx=0)
+        k = int(ref[3].item())
+        rb_s = ops.build_rulebook(ref[1][:k].contiguous(), 1, shape, 3, 1, 0, 1, True)
+        rb_c = ops.build_rulebook(ref[1][:k].contiguous(), 1, shape, 3, 2, 1, 1, False)
+        assert L.lcf_set_option(_lib.OPT_WS_CLEAN, 1) == 0
+        try:
+            got = ops.voxelize(pts, synth.VOXEL_SIZE, synth.PC_RANGE, T, MV, batch_idx=0, ws=vws)
+            kd = got[3]
+            nbr = torch.empty((MV, 27), dtype=torch.int32, device=cuda)
+            check(L.lcf_rulebook_subm(P(got[1]), MV, P(kd), 1, i3(shape), i3(ks), i3(one), P(nbr),
+                                      P(sws), sws.numel(), st))
+            cap = rb_c.k_out + 100
+            oc = torch.empty((cap, 4), dtype=torch.int32, device=cuda)
+            ko = torch.zeros(1, dtype=torch.int32, device=cuda)
+            flag = torch.zeros(1, dtype=torch.int32, device=cuda)
+            onbr = torch.empty((cap, 27), dtype=torch.int32, device=cuda)
+            geo = (1, i3(shape), i3(ks), i3(two), i3(one), i3(one))
+            check(L.lcf_rulebook_conv_discover(P(got[1]), MV, P(kd), *geo, P(oc), cap, P(ko),
+                                               P(flag), P(cws), cws.numel(), st))
+            check(L.lcf_rulebook_conv_fill(P(got[1]), MV, P(kd), *geo, cap, P(ko), P(onbr), None,
+                                           P(cws), cws.numel(), st))
+        finally:
+            L.lcf_set_option(_lib.OPT_WS_CLEAN, 0)
+        reset()  # re-arm for the next frame
+        for a, b in zip(got, ref):
+            assert torch.equal(a, b)
+        assert torch.equal(nbr[:k], rb_s.out_nbr)
+        assert int(ko.item()) == rb_c.k_out and int(flag.item()) == 0
+        assert torch.equal(oc[:rb_c.k_out], rb_c.out_indices)
+        assert torch.equal(onbr[:rb_c.k_out], rb_c.out_nbr)
