@@ -228,6 +228,25 @@ int lcf_vfe_fused(const float *voxels, const int *num, int k, const int *k_dev, 
                   const float *w2img, const float *sc2, const float *sh2, const float *w3img,
                   const float *sc3, const float *sh3, float *out, void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Training-mode BatchNorm1d + ReLU over the active rows of a sparse tensor.
+ * Replaces: the nn.BatchNorm1d(eps=1e-3, momentum=0.01) -> nn.ReLU pair between the sparse convs
+ * (second/pytorch/models/middle.py:124-125,147-148; torch's native_batch_norm /
+ * native_batch_norm_backward + threshold_backward), batch statistics over the K rows.
+ * x, y, dy, dx [k,c] fp32, c a multiple of 4 and <= 128 (else LCF_ERR_UNSUPPORTED); gamma / beta
+ * [c] or NULL (1 / 0); relu 0 = plain BatchNorm.
+ * fwd: y = relu((x - mean) * inv * gamma + beta); stats [3c] = mean, biased variance,
+ *      inv = 1/sqrt(var + eps) (the caller updates running statistics from it).
+ * bwd: with g = dy * (y > 0): dx, dgamma = sum g * xhat, dbeta = sum g (either may be NULL).
+ * Deterministic (fixed partition of the rows, fixed order).  ws: lcf_bn_workspace_bytes. */
+size_t lcf_bn_workspace_bytes(int k, int c);
+int lcf_bn_relu_fwd(const float *x, int k, int c, const float *gamma, const float *beta,
+                    float eps, int relu, float *y, float *stats, void *ws, size_t ws_bytes,
+                    void *stream);
+int lcf_bn_relu_bwd(const float *x, const float *y, const float *dy, int k, int c,
+                    const float *gamma, const float *stats, int relu, float *dx, float *dgamma,
+                    float *dbeta, void *ws, size_t ws_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -68,6 +68,12 @@ SYMBOLS = {
     "lcf_fill_u32": (c_int, [c_void_p, ctypes.c_uint32, c_size_t, c_void_p]),
     "lcf_vfe_fused": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int,
                               c_int] + [c_void_p] * 11),
+    "lcf_bn_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "lcf_bn_relu_fwd": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, ctypes.c_float, c_int,
+                                c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "lcf_bn_relu_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p,
+                                c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
+                                c_void_p]),
 }
 
 # lcf_set_option keys (include/lcf.h)

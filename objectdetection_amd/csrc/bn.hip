@@ -1,0 +1,277 @@
+// bn.hip -- training-mode BatchNorm1d + ReLU over the active voxels of a sparse tensor, the pair
+// that sits between every two sparse convs of the middle extractor
+// (second/pytorch/models/middle.py:124-125,147-148: BatchNorm1d(eps=1e-3, momentum=0.01), ReLU;
+// SURVEY.md section 8 row a13).  Four HBM-streaming kernels over rows [K, C] fp32:
+//   forward   stats partials -> (finalise +) y = relu(x * scale + shift)
+//   backward  reduce partials of g = dy * (y > 0): sum g, sum g * xhat -> (finalise +) dx
+// Per-channel sums are taken over a FIXED partition of the rows in a fixed order (per-thread
+// registers -> LDS tree -> partials in HBM -> double-precision sum of the partials), so results
+// are run-to-run bit-identical; a one-wave-per-column kernel sums the partials in between.
+#include "common.h"
+
+#define BN_BLOCK 256
+#define BN_MAX_C 128
+#define BN_MAX_PARTS 512
+
+// thread -> (row lane rl, float4 column group c4); a block walks rows rl, rl + RL, ... of its chunk
+struct BnMap {
+    int c4n; // float4 groups per row
+    int rl;  // row lane of this thread
+    int c4;  // column group of this thread
+    int RL;  // row lanes per block
+};
+
+__device__ __forceinline__ BnMap bn_map(int c)
+{
+    BnMap m;
+    m.c4n = c >> 2;
+    m.RL = BN_BLOCK / m.c4n;
+    m.rl = threadIdx.x / m.c4n;
+    m.c4 = threadIdx.x % m.c4n;
+    return m;
+}
+
+// block-level sum of two float4 per thread over the row lanes -> part[0:c] and part[c:2c]
+__device__ __forceinline__ void bn_block_reduce(const BnMap &m, int c, float4 a, float4 b,
+                                                float *lds, float *part)
+{
+    // lds [RL][2c]
+    float4 *l4 = reinterpret_cast<float4 *>(lds);
+    const bool live = m.rl < m.RL;
+    if (live) {
+        l4[m.rl * (2 * m.c4n) + m.c4] = a;
+        l4[m.rl * (2 * m.c4n) + m.c4n + m.c4] = b;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 2 * c; e += BN_BLOCK) {
+        float s = 0.f;
+        for (int r = 0; r < m.RL; ++r) s += lds[r * 2 * c + e];
+        part[e] = s;
+    }
+}
+
+// ---- forward 1: partial sums of x and x^2
+__global__ void __launch_bounds__(BN_BLOCK)
+bn_stats_kernel(const float *__restrict__ x, int k, int c, int rows_per_block,
+                float *__restrict__ parts)
+{
+    __shared__ __align__(16) float lds[BN_BLOCK * 8];
+    const BnMap m = bn_map(c);
+    const int r0 = blockIdx.x * rows_per_block;
+    const int r1 = min(k, r0 + rows_per_block);
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f), q = s;
+    if (m.rl < m.RL) {
+        for (int r = r0 + m.rl; r < r1; r += m.RL) {
+            const float4 v = reinterpret_cast<const float4 *>(x + (size_t)r * c)[m.c4];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+            q.x += v.x * v.x; q.y += v.y * v.y; q.z += v.z * v.z; q.w += v.w * v.w;
+        }
+    }
+    bn_block_reduce(m, c, s, q, lds, parts + (size_t)blockIdx.x * 2 * c);
+}
+
+// ---- sums[e] = sum over the partials of column e (double); one wave per column
+__global__ void __launch_bounds__(64)
+bn_finalize_kernel(const float *__restrict__ parts, int nparts, int c2, double *__restrict__ sums)
+{
+    const int e = blockIdx.x;
+    double s = 0.0;
+    for (int p = threadIdx.x; p < nparts; p += 64) s += (double)parts[(size_t)p * c2 + e];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) s += __shfl_down(s, d, 64);
+    if (threadIdx.x == 0) sums[e] = s;
+}
+
+// ---- forward 2: mean / biased var from the partials, y = relu(x * scale + shift)
+__global__ void __launch_bounds__(BN_BLOCK)
+bn_apply_relu_kernel(const float *__restrict__ x, int k, int c, int rows_per_block,
+                     const double *__restrict__ sums,
+                     const float *__restrict__ gamma, const float *__restrict__ beta, float eps,
+                     int relu, float *__restrict__ y, float *__restrict__ stats)
+{
+    __shared__ __align__(16) float sc[BN_MAX_C], sh[BN_MAX_C];
+    for (int e = threadIdx.x; e < c; e += BN_BLOCK) {
+        const double mean = sums[e] / k;
+        double var = sums[c + e] / k - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float inv = (float)(1.0 / sqrt(var + (double)eps));
+        const float g = gamma ? gamma[e] : 1.f;
+        sc[e] = g * inv;
+        sh[e] = (beta ? beta[e] : 0.f) - (float)mean * g * inv;
+        if (blockIdx.x == 0) {
+            stats[e] = (float)mean;
+            stats[c + e] = (float)var;
+            stats[2 * c + e] = inv;
+        }
+    }
+    __syncthreads();
+    const BnMap m = bn_map(c);
+    if (m.rl >= m.RL) return;
+    const float4 a = reinterpret_cast<const float4 *>(sc)[m.c4];
+    const float4 b = reinterpret_cast<const float4 *>(sh)[m.c4];
+    const int r0 = blockIdx.x * rows_per_block;
+    const int r1 = min(k, r0 + rows_per_block);
+    for (int r = r0 + m.rl; r < r1; r += m.RL) {
+        float4 v = reinterpret_cast<const float4 *>(x + (size_t)r * c)[m.c4];
+        v.x = v.x * a.x + b.x; v.y = v.y * a.y + b.y;
+        v.z = v.z * a.z + b.z; v.w = v.w * a.w + b.w;
+        if (relu) {
+            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f);
+            v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        }
+        reinterpret_cast<float4 *>(y + (size_t)r * c)[m.c4] = v;
+    }
+}
+
+// ---- backward 1: partial sums of g = dy * (y > 0) and of g * xhat, xhat = (x - mean) * inv
+__global__ void __launch_bounds__(BN_BLOCK)
+bn_bwd_reduce_kernel(const float *__restrict__ x, const float *__restrict__ y,
+                     const float *__restrict__ dy, int k, int c, int rows_per_block,
+                     const float *__restrict__ stats, int relu, float *__restrict__ parts)
+{
+    __shared__ __align__(16) float lds[BN_BLOCK * 8];
+    const BnMap m = bn_map(c);
+    const int r0 = blockIdx.x * rows_per_block;
+    const int r1 = min(k, r0 + rows_per_block);
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f), q = s;
+    if (m.rl < m.RL) {
+        const float4 mean = reinterpret_cast<const float4 *>(stats)[m.c4];
+        const float4 inv = reinterpret_cast<const float4 *>(stats + 2 * c)[m.c4];
+        for (int r = r0 + m.rl; r < r1; r += m.RL) {
+            const float4 xv = reinterpret_cast<const float4 *>(x + (size_t)r * c)[m.c4];
+            float4 g = reinterpret_cast<const float4 *>(dy + (size_t)r * c)[m.c4];
+            if (relu) {
+                const float4 yv = reinterpret_cast<const float4 *>(y + (size_t)r * c)[m.c4];
+                g.x = yv.x > 0.f ? g.x : 0.f; g.y = yv.y > 0.f ? g.y : 0.f;
+                g.z = yv.z > 0.f ? g.z : 0.f; g.w = yv.w > 0.f ? g.w : 0.f;
+            }
+            s.x += g.x; s.y += g.y; s.z += g.z; s.w += g.w;
+            q.x += g.x * (xv.x - mean.x) * inv.x; q.y += g.y * (xv.y - mean.y) * inv.y;
+            q.z += g.z * (xv.z - mean.z) * inv.z; q.w += g.w * (xv.w - mean.w) * inv.w;
+        }
+    }
+    bn_block_reduce(m, c, s, q, lds, parts + (size_t)blockIdx.x * 2 * c);
+}
+
+// ---- backward 2: dx = gamma * inv * (g - mean(g) - xhat * mean(g * xhat)); dgamma, dbeta
+__global__ void __launch_bounds__(BN_BLOCK)
+bn_bwd_apply_kernel(const float *__restrict__ x, const float *__restrict__ y,
+                    const float *__restrict__ dy, int k, int c, int rows_per_block,
+                    const float *__restrict__ stats, const double *__restrict__ sums,
+                    const float *__restrict__ gamma, int relu, float *__restrict__ dx,
+                    float *__restrict__ dgamma, float *__restrict__ dbeta)
+{
+    __shared__ __align__(16) float mg[BN_MAX_C], mgx[BN_MAX_C], gi[BN_MAX_C];
+    for (int e = threadIdx.x; e < c; e += BN_BLOCK) {
+        const double sg = sums[e];
+        const double sgx = sums[c + e];
+        mg[e] = (float)(sg / k);
+        mgx[e] = (float)(sgx / k);
+        gi[e] = (gamma ? gamma[e] : 1.f) * stats[2 * c + e];
+        if (blockIdx.x == 0) {
+            if (dgamma) dgamma[e] = (float)sgx;
+            if (dbeta) dbeta[e] = (float)sg;
+        }
+    }
+    __syncthreads();
+    const BnMap m = bn_map(c);
+    if (m.rl >= m.RL) return;
+    const float4 mean = reinterpret_cast<const float4 *>(stats)[m.c4];
+    const float4 inv = reinterpret_cast<const float4 *>(stats + 2 * c)[m.c4];
+    const float4 a = reinterpret_cast<const float4 *>(mg)[m.c4];
+    const float4 b = reinterpret_cast<const float4 *>(mgx)[m.c4];
+    const float4 w = reinterpret_cast<const float4 *>(gi)[m.c4];
+    const int r0 = blockIdx.x * rows_per_block;
+    const int r1 = min(k, r0 + rows_per_block);
+    for (int r = r0 + m.rl; r < r1; r += m.RL) {
+        const float4 xv = reinterpret_cast<const float4 *>(x + (size_t)r * c)[m.c4];
+        float4 g = reinterpret_cast<const float4 *>(dy + (size_t)r * c)[m.c4];
+        if (relu) {
+            const float4 yv = reinterpret_cast<const float4 *>(y + (size_t)r * c)[m.c4];
+            g.x = yv.x > 0.f ? g.x : 0.f; g.y = yv.y > 0.f ? g.y : 0.f;
+            g.z = yv.z > 0.f ? g.z : 0.f; g.w = yv.w > 0.f ? g.w : 0.f;
+        }
+        float4 o;
+        o.x = w.x * (g.x - a.x - (xv.x - mean.x) * inv.x * b.x);
+        o.y = w.y * (g.y - a.y - (xv.y - mean.y) * inv.y * b.y);
+        o.z = w.z * (g.z - a.z - (xv.z - mean.z) * inv.z * b.z);
+        o.w = w.w * (g.w - a.w - (xv.w - mean.w) * inv.w * b.w);
+        reinterpret_cast<float4 *>(dx + (size_t)r * c)[m.c4] = o;
+    }
+}
+
+// rows per block / number of partials for k rows: enough blocks to fill the chip, at most
+// BN_MAX_PARTS partials
+static void bn_partition(int k, int *rows_per_block, int *nparts)
+{
+    int nb = (k + 255) / 256;
+    if (nb > BN_MAX_PARTS) nb = BN_MAX_PARTS;
+    if (nb < 1) nb = 1;
+    int rpb = (k + nb - 1) / nb;
+    *rows_per_block = rpb;
+    *nparts = (k + rpb - 1) / rpb;
+}
+
+static int bn_check(int k, int c)
+{
+    if (k <= 0 || c <= 0) return LCF_ERR_ARG;
+    if ((c & 3) || c > BN_MAX_C) return LCF_ERR_UNSUPPORTED;
+    return LCF_OK;
+}
+
+extern "C" size_t lcf_bn_workspace_bytes(int k, int c)
+{
+    if (k <= 0 || c <= 0) return 0;
+    return (size_t)BN_MAX_PARTS * 2 * c * sizeof(float) + (size_t)2 * c * sizeof(double);
+}
+
+extern "C" int lcf_bn_relu_fwd(const float *x, int k, int c, const float *gamma,
+                               const float *beta, float eps, int relu, float *y, float *stats,
+                               void *ws, size_t ws_bytes, void *stream)
+{
+    int rc = bn_check(k, c);
+    if (rc) return rc;
+    if (!x || !y || !stats || !ws) return LCF_ERR_ARG;
+    if (((uintptr_t)x & 15) || ((uintptr_t)y & 15) || ((uintptr_t)stats & 15)) return LCF_ERR_ARG;
+    if (ws_bytes < lcf_bn_workspace_bytes(k, c)) return LCF_ERR_WORKSPACE;
+    int rpb, np;
+    bn_partition(k, &rpb, &np);
+    hipStream_t st = (hipStream_t)stream;
+    float *parts = (float *)ws;
+    double *sums = (double *)((char *)ws + (size_t)BN_MAX_PARTS * 2 * c * sizeof(float));
+    bn_stats_kernel<<<np, BN_BLOCK, 0, st>>>(x, k, c, rpb, parts);
+    LCF_CHECK_LAUNCH();
+    bn_finalize_kernel<<<2 * c, 64, 0, st>>>(parts, np, 2 * c, sums);
+    LCF_CHECK_LAUNCH();
+    bn_apply_relu_kernel<<<np, BN_BLOCK, 0, st>>>(x, k, c, rpb, sums, gamma, beta, eps, relu, y,
+                                                 stats);
+    LCF_CHECK_LAUNCH();
+    return LCF_OK;
+}
+
+extern "C" int lcf_bn_relu_bwd(const float *x, const float *y, const float *dy, int k, int c,
+                               const float *gamma, const float *stats, int relu, float *dx,
+                               float *dgamma, float *dbeta, void *ws, size_t ws_bytes,
+                               void *stream)
+{
+    int rc = bn_check(k, c);
+    if (rc) return rc;
+    if (!x || !dy || !dx || !stats || !ws || (relu && !y)) return LCF_ERR_ARG;
+    if (((uintptr_t)x & 15) || ((uintptr_t)dy & 15) || ((uintptr_t)dx & 15) ||
+        ((uintptr_t)y & 15) || ((uintptr_t)stats & 15))
+        return LCF_ERR_ARG;
+    if (ws_bytes < lcf_bn_workspace_bytes(k, c)) return LCF_ERR_WORKSPACE;
+    int rpb, np;
+    bn_partition(k, &rpb, &np);
+    hipStream_t st = (hipStream_t)stream;
+    float *parts = (float *)ws;
+    double *sums = (double *)((char *)ws + (size_t)BN_MAX_PARTS * 2 * c * sizeof(float));
+    bn_bwd_reduce_kernel<<<np, BN_BLOCK, 0, st>>>(x, y, dy, k, c, rpb, stats, relu, parts);
+    LCF_CHECK_LAUNCH();
+    bn_finalize_kernel<<<2 * c, 64, 0, st>>>(parts, np, 2 * c, sums);
+    LCF_CHECK_LAUNCH();
+    bn_bwd_apply_kernel<<<np, BN_BLOCK, 0, st>>>(x, y, dy, k, c, rpb, stats, sums, gamma, relu, dx,
+                                                dgamma, dbeta);
+    LCF_CHECK_LAUNCH();
+    return LCF_OK;
+}

@@ -44,15 +44,13 @@ class SparseFrontEnd(nn.Module):
     def voxelize(self, clouds):
         """-> voxels [sumK,T,F], num_points [sumK], coors [sumK,4] (b,z,y,x)  (merge_second_batch,
         second/data/preprocess.py:21-55, on the device)."""
-        vs, ns, cs = [], [], []
-        for b, pts in enumerate(clouds):
-            res = self.voxel_generator.generate_device(pts, self.max_voxels)
-            k = int(res["voxel_num"].item())
-            vs.append(res["voxels"][:k])
-            ns.append(res["num_points_per_voxel"][:k])
-            c = res["coordinates"][:k]
-            cs.append(torch.cat([torch.full((k, 1), b, dtype=torch.int32, device=c.device), c],
-                                dim=1))
+        # every scene is enqueued first; the voxel counts come back in ONE synchronisation
+        res = [self.voxel_generator.generate_device(pts, self.max_voxels, batch_idx=b)
+               for b, pts in enumerate(clouds)]
+        ks = torch.cat([r["voxel_num"] for r in res]).tolist()
+        vs = [r["voxels"][:k] for r, k in zip(res, ks)]
+        ns = [r["num_points_per_voxel"][:k] for r, k in zip(res, ks)]
+        cs = [r["coordinates"][:k] for r, k in zip(res, ks)]
         if len(clouds) == 1:
             return vs[0], ns[0], cs[0]
         return torch.cat(vs), torch.cat(ns), torch.cat(cs)

@@ -430,3 +430,65 @@ def vfe_fused(voxels, num_points, lin, k_dev=None, out=None):
         return None
     check(rc)
     return out
+
+
+# ------------------------------------------------------------------ BatchNorm1d + ReLU (training)
+
+def bn_relu_supported(x):
+    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.shape[0] > 0
+            and x.shape[1] % 4 == 0 and x.shape[1] <= 128)
+
+
+class BNReLUFunction(torch.autograd.Function):
+    """y = relu(batch_norm(x)) with batch statistics over the rows of x [K, C] (include/lcf.h:
+    lcf_bn_relu_fwd / _bwd).  Returns (y, mean, biased var); the module updates its running
+    statistics from the latter two."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, relu):
+        L = _lib.lib()
+        x = x.contiguous()
+        k, c = x.shape
+        y = torch.empty_like(x)
+        stats = torch.empty((3 * c,), dtype=torch.float32, device=x.device)
+        ws = _ws(L.lcf_bn_workspace_bytes(k, c), x.device)
+        g = None if gamma is None else gamma.detach().float().contiguous()
+        b = None if beta is None else beta.detach().float().contiguous()
+        check(L.lcf_bn_relu_fwd(_ptr(x), k, c, _ptr(g), _ptr(b), float(eps), int(relu), _ptr(y),
+                                _ptr(stats), _ptr(ws), ws.numel(), _stream()))
+        ctx.save_for_backward(x, y, g, stats)
+        ctx.relu = bool(relu)
+        ctx.has = (gamma is not None, beta is not None)
+        ctx.mark_non_differentiable(stats)
+        return y, stats
+
+    @staticmethod
+    def backward(ctx, dy, _dstats):
+        L = _lib.lib()
+        x, y, g, stats = ctx.saved_tensors
+        k, c = x.shape
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        dg = torch.empty((c,), dtype=torch.float32, device=x.device) if ctx.has[0] else None
+        db = torch.empty((c,), dtype=torch.float32, device=x.device) if ctx.has[1] else None
+        ws = _ws(L.lcf_bn_workspace_bytes(k, c), x.device)
+        check(L.lcf_bn_relu_bwd(_ptr(x), _ptr(y), _ptr(dy), k, c, _ptr(g), _ptr(stats),
+                                int(ctx.relu), _ptr(dx), _ptr(dg), _ptr(db), _ptr(ws), ws.numel(),
+                                _stream()))
+        return dx, dg, db, None, None
+
+
+def bn_relu_train(norm, x, relu=True):
+    """nn.BatchNorm1d `norm` in training mode (+ ReLU) on x [K, C]: the fused kernels, then the
+    running-statistics update nn.BatchNorm1d would have done (unbiased variance, momentum)."""
+    y, stats = BNReLUFunction.apply(x, norm.weight, norm.bias, norm.eps, relu)
+    if norm.track_running_stats:
+        with torch.no_grad():
+            k, c = x.shape
+            norm.num_batches_tracked += 1
+            m = norm.momentum
+            if m is None:
+                m = 1.0 / float(norm.num_batches_tracked)
+            norm.running_mean.mul_(1 - m).add_(stats[:c], alpha=m)
+            norm.running_var.mul_(1 - m).add_(stats[c:2 * c], alpha=m * k / max(k - 1, 1))
+    return y

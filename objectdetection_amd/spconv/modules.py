@@ -5,6 +5,7 @@ from collections import OrderedDict
 import torch
 from torch import nn
 
+from .. import ops
 from .tensor import SparseConvTensor
 
 
@@ -39,9 +40,13 @@ class SparseSequential(SparseModule):
     MI355X addition: when gradients are off and the modules are in eval
     mode, a ``sparse conv -> BatchNorm1d -> ReLU`` run is executed as ONE kernel launch with the
     normalisation folded into the conv epilogue (exact in inference: BN is affine there).
-    Set ``fuse_inference = False`` to run module by module.
+    Set ``fuse_inference = False`` to run module by module.  In training a
+    ``BatchNorm1d (training) -> ReLU`` pair on the features runs as the fused streaming kernels of
+    ``ops.bn_relu_train`` (same values and running statistics as the two torch modules;
+    ``fuse_training = False`` to turn it off).
     """
     fuse_inference = True
+    fuse_training = True
 
     def __init__(self, *args, **kwargs):
         super().__init__()
@@ -112,6 +117,13 @@ class SparseSequential(SparseModule):
                 input = module(input)
             elif isinstance(input, SparseConvTensor):
                 if input.indices.shape[0] != 0:
+                    if (self.fuse_training and isinstance(module, nn.BatchNorm1d)
+                            and module.training and torch.is_grad_enabled()
+                            and ops.bn_relu_supported(input.features)):
+                        relu = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
+                        input.features = ops.bn_relu_train(module, input.features, relu)
+                        i += 2 if relu else 1
+                        continue
                     input.features = module(input.features)
             else:
                 input = module(input)

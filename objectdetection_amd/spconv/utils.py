@@ -58,12 +58,14 @@ class VoxelGeneratorV2:
         self._device = device
 
     # ---- device path
-    def generate_device(self, points, max_voxels=None):
+    def generate_device(self, points, max_voxels=None, batch_idx=None):
         """points: [N,F] float32 cuda tensor -> dict of cuda tensors padded to max_voxels, with
-        ``voxel_num`` a [1] int32 cuda tensor (no synchronisation)."""
+        ``voxel_num`` a [1] int32 cuda tensor (no synchronisation).  ``batch_idx`` not None:
+        coordinates come out as [max_voxels,4] (batch_idx, z, y, x), merge_second_batch's form."""
         mv = int(max_voxels or self._max_voxels)
         voxels, coors, num, vnum = ops.voxelize(points, self._voxel_size, self._point_cloud_range,
-                                                self._max_num_points, mv, self._cap_mode)
+                                                self._max_num_points, mv, self._cap_mode,
+                                                batch_idx=batch_idx)
         if self._full_mean:
             # fill the empty slots of a voxel with the mean of its points
             n = num.clamp(min=1).view(-1, 1, 1).float()

@@ -215,3 +215,42 @@ def test_bf16_forward_and_dgrad_match_oracle(oracle, cuda, cin, cout, subm):
     a = ops.conv_forward_bf16(xe, ops.weight_image_bf16(we), rb.out_nbr, rb.k_out, 27, cin, cout)
     b = ops.conv_forward(xe, ops.weight_image(we), rb.out_nbr, rb.k_out, 27, cin, cout)
     assert rel_err(a.cpu().numpy(), b.cpu().numpy()) < 1e-5
+
+
+@pytest.mark.parametrize("k,c", [(1, 16), (37, 16), (5000, 32), (150001, 64), (3000, 128),
+                                 (777, 12)])
+@pytest.mark.parametrize("relu", [True, False])
+def test_bn_relu_training_kernels_match_torch(cuda, k, c, relu):
+    """lcf_bn_relu_fwd / _bwd (training BatchNorm1d + ReLU between the sparse convs,
+    middle.py:124-125) against torch's BatchNorm1d + ReLU in fp32: output, input / weight / bias
+    gradients, running statistics; run-to-run bit-identical."""
+    import copy
+    torch.manual_seed(k + c)
+    bn = torch.nn.BatchNorm1d(c, eps=1e-3, momentum=0.01).to(cuda).train()
+    torch.nn.init.uniform_(bn.weight, 0.5, 1.5)
+    torch.nn.init.normal_(bn.bias, std=0.3)
+    ref = copy.deepcopy(bn)
+    x = (torch.randn(k, c, device=cuda) * 2 + 0.7)
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    g = torch.randn(k, c, device=cuda)
+    ya = ops.bn_relu_train(bn, xa, relu)
+    if k > 1:
+        yb = ref(xb)
+        yb = torch.relu(yb) if relu else yb
+    else:  # torch refuses a batch of one in training; the kernels give the k = 1 limit (x - x = 0)
+        yb = torch.relu(ref.bias.expand(1, c)) if relu else ref.bias.expand(1, c).clone()
+    tol = 2e-5
+    scale = max(float(yb.detach().abs().max()), 1e-6)
+    assert float((ya - yb).detach().abs().max()) / scale < tol
+    if k > 1:
+        (ya * g).sum().backward()
+        (yb * g).sum().backward()
+        for a, b, name in [(xa.grad, xb.grad, "dx"), (bn.weight.grad, ref.weight.grad, "dgamma"),
+                           (bn.bias.grad, ref.bias.grad, "dbeta")]:
+            assert float((a - b).abs().max()) / max(float(b.abs().max()), 1e-6) < 1e-4, name
+        assert torch.allclose(bn.running_mean, ref.running_mean, rtol=1e-5, atol=1e-6)
+        assert torch.allclose(bn.running_var, ref.running_var, rtol=1e-5, atol=1e-6)
+        assert int(bn.num_batches_tracked) == 1
+    again = ops.bn_relu_train(copy.deepcopy(ref), xa.detach(), relu)
+    again2 = ops.bn_relu_train(copy.deepcopy(ref), xa.detach(), relu)
+    assert torch.equal(again, again2)
