@@ -247,6 +247,30 @@ int lcf_bn_relu_bwd(const float *x, const float *y, const float *dy, int k, int 
                     const float *gamma, const float *stats, int relu, float *dx, float *dgamma,
                     float *dbeta, void *ws, size_t ws_bytes, void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Rotated / axis-aligned IoU and non-maximum suppression (the predict-time
+ * post-processing that the reference runs through the host).
+ * lcf_rotate_iou replaces rotate_iou_gpu / rotate_iou_gpu_eval
+ *   (second/core/non_max_suppression/nms_gpu.py:478-640): boxes [n,5], qboxes [k,5] as
+ *   (cx, cy, w, h, angle), or with corners != 0 [n,8] / [k,8] corner coordinates (the form
+ *   spconv.utils.rbbox_iou takes); iou [n,k]; criterion -1: IoU, 0: inter / area(qbox),
+ *   1: inter / area(box), 2: intersection area.
+ * lcf_nms replaces nms_gpu / rotate_nms_gpu (nms_gpu.py:129-163, :440-475: pairwise kernel +
+ *   the host loop nms_postprocess) and spconv's non_max_suppression_cpu /
+ *   rotate_non_max_suppression_cpu as called from second/pytorch/core/box_torch_ops.py:473-515.
+ *   dets: n rows of `stride` floats ALREADY sorted by descending score; mode 0: (x1, y1, x2, y2)
+ *   with the +eps pixel convention (eps = 1 in the reference's callers), mode 1: (cx, cy, w, h,
+ *   angle), mode 2: 8 corner coordinates.  A box is dropped when an earlier kept box overlaps it by more than thresh
+ *   (inclusive != 0: at least thresh, spconv's / nms_jit's test).  keep [min(n, max_keep)] gets
+ *   the kept positions in order, num_keep [1] their number (device memory; max_keep <= 0: all).
+ *   ws: lcf_nms_workspace_bytes(n) (the n x n/64 suppression matrix); n <= 65536. */
+int lcf_rotate_iou(const float *boxes, int n, const float *qboxes, int k, int corners,
+                   int criterion, float *iou, void *stream);
+size_t lcf_nms_workspace_bytes(int n);
+int lcf_nms(const float *dets, int n, int stride, int mode, float thresh, float eps,
+            int inclusive, int max_keep, int *keep, int *num_keep, void *ws, size_t ws_bytes,
+            void *stream);
+
 #ifdef __cplusplus
 }
 #endif

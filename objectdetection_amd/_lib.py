@@ -68,6 +68,11 @@ SYMBOLS = {
     "lcf_fill_u32": (c_int, [c_void_p, ctypes.c_uint32, c_size_t, c_void_p]),
     "lcf_vfe_fused": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int,
                               c_int] + [c_void_p] * 11),
+    "lcf_rotate_iou": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p,
+                               c_void_p]),
+    "lcf_nms_workspace_bytes": (c_size_t, [c_int]),
+    "lcf_nms": (c_int, [c_void_p, c_int, c_int, c_int, ctypes.c_float, ctypes.c_float, c_int,
+                        c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "lcf_bn_workspace_bytes": (c_size_t, [c_int, c_int]),
     "lcf_bn_relu_fwd": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, ctypes.c_float, c_int,
                                 c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),

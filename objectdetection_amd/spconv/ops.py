@@ -1,6 +1,5 @@
 """spconv.ops: the functional layer under the modules (get_indice_pairs, indice_conv) plus the
-post-processing names that must exist at import time (second/pytorch/core/box_torch_ops.py:488
-calls spconv.ops.nms -- out of the front-end scope)."""
+axis-aligned NMS that second/pytorch/core/box_torch_ops.py:488 calls."""
 import torch
 
 from .. import ops as _ops
@@ -41,6 +40,13 @@ def indice_conv(features, filters, rulebook):
 
 
 def nms(boxes, scores, pre_max_size, post_max_size, thresh, eps):
-    raise NotImplementedError(
-        "spconv.ops.nms is post-processing, outside the sparse front end this package provides; "
-        "use second.pytorch.core.box_torch_ops.nms")
+    """Axis-aligned NMS as called by box_torch_ops.nms (box_torch_ops.py:488): boxes [N,4]
+    (x1,y1,x2,y2), pre / post sizes <= 0 meaning "all"; the reference passes CPU tensors, the work
+    runs on the GPU and the kept indices come back on the input's device."""
+    from .. import nms as _nms
+    dev = boxes.device
+    if not boxes.is_cuda:
+        boxes, scores = boxes.to(_nms._dev()), scores.to(_nms._dev())
+    keep = _nms.nms(boxes, scores, pre_max_size if pre_max_size > 0 else None,
+                    post_max_size if post_max_size > 0 else None, thresh, eps)
+    return keep.to(dev)

@@ -1,27 +1,78 @@
 """spconv.utils: VoxelGeneratorV2 (second/builder/voxel_builder.py:23-33; used at
 second/data/preprocess.py:621-639, second/pytorch/train.py:60,
 second/pytorch/builder/second_builder.py:30-31, second/pytorch/models/voxelnet.py:147-148) and
-the import-time names of the IoU/NMS helpers (out of scope: post-processing)."""
+the IoU / NMS helpers (rbbox_iou, non_max_suppression*, on the GPU through objectdetection_amd.nms)."""
 import numpy as np
 import torch
 
 from .. import ops
 
 
-def _out_of_scope(name):
-    def fn(*a, **k):
-        raise NotImplementedError(
-            f"spconv.utils.{name} is post-processing, outside the sparse front end "
-            "(SURVEY.md section 2); it is exported only so that imports succeed")
-    fn.__name__ = name
-    return fn
+# ---- IoU / NMS helpers of spconv.utils, on the GPU (objectdetection_amd/nms.py; SURVEY.md
+# section 8f-3).  spconv's C++ source is not part of the reference tree: argument meaning follows
+# the call sites (second/core/box_np_ops.py:10-34, second/core/non_max_suppression/nms_cpu.py:11-32,
+# nms_gpu.py:10-19); exact tie / threshold behaviour of the originals is unpinned.
+
+def _corners(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.float32).reshape(-1, 8))
 
 
-rbbox_iou = _out_of_scope("rbbox_iou")
-rbbox_intersection = _out_of_scope("rbbox_intersection")
-non_max_suppression = _out_of_scope("non_max_suppression")
-non_max_suppression_cpu = _out_of_scope("non_max_suppression_cpu")
-rotate_non_max_suppression_cpu = _out_of_scope("rotate_non_max_suppression_cpu")
+def _pair_matrix(box_corners, qbox_corners, standup_iou, standup_thresh, criterion):
+    from .. import nms as _nms
+    b, q = _corners(box_corners), _corners(qbox_corners)
+    if b.shape[0] == 0 or q.shape[0] == 0:
+        return np.zeros((b.shape[0], q.shape[0]), dtype=np.float32)
+    dev = _nms._dev()
+    out = _nms.rotate_iou(torch.from_numpy(b).to(dev), torch.from_numpy(q).to(dev), criterion,
+                          corners=True).cpu().numpy()
+    if standup_iou is not None:  # the originals skip pairs whose stand-up boxes do not overlap
+        out[np.asarray(standup_iou) <= standup_thresh] = 0.0
+    return out
+
+
+def rbbox_iou(box_corners, qbox_corners, standup_iou=None, standup_thresh=0.0):
+    """box_corners [N,4,2], qbox_corners [K,4,2] -> rotated IoU [N,K] (box_np_ops.py:10-21)."""
+    return _pair_matrix(box_corners, qbox_corners, standup_iou, standup_thresh, -1)
+
+
+def rbbox_intersection(box_corners, qbox_corners, standup_iou=None, standup_thresh=0.0):
+    """-> intersection areas [N,K] (box_np_ops.py:23-34)."""
+    return _pair_matrix(box_corners, qbox_corners, standup_iou, standup_thresh, 2)
+
+
+def _nms_np(rows, order, thresh, eps, mode):
+    from .. import nms as _nms
+    rows = np.asarray(rows, dtype=np.float32)
+    order = np.asarray(order).astype(np.int64)
+    if order.shape[0] == 0:
+        return []
+    d = torch.from_numpy(np.ascontiguousarray(rows[order].reshape(order.shape[0], -1)))
+    keep = _nms.nms_sorted(d.to(_nms._dev()), mode, thresh, eps=eps, inclusive=True)
+    return order[keep.cpu().numpy()].astype(np.int32).tolist()
+
+
+def non_max_suppression_cpu(boxes, order, thresh, eps=0.0):
+    """boxes [N,>=4] (x1,y1,x2,y2,...), order: indices by descending score -> kept indices."""
+    return _nms_np(boxes, order, thresh, eps, 0)
+
+
+def rotate_non_max_suppression_cpu(box_corners, order, standup_iou, thresh):
+    """box_corners [N,4,2] -> kept indices (nms_cpu.py:17-32).  ``standup_iou`` (a pre-filter in
+    the original) is not needed: every pair is evaluated."""
+    return _nms_np(np.asarray(box_corners).reshape(-1, 8), order, thresh, 0.0, 2)
+
+
+def non_max_suppression(boxes, keep_out, nms_overlap_thresh, device_id=0):
+    """boxes [N,5] sorted by descending score; fills keep_out, returns the number kept
+    (nms_gpu.py:10-19 nms_gpu_cc)."""
+    from .. import nms as _nms
+    boxes = np.asarray(boxes, dtype=np.float32)
+    if boxes.shape[0] == 0:
+        return 0
+    keep = _nms.nms_sorted(torch.from_numpy(boxes).to(_nms._dev(device_id)), 0,
+                           nms_overlap_thresh, eps=1.0, inclusive=False).cpu().numpy()
+    keep_out[:keep.shape[0]] = keep
+    return int(keep.shape[0])
 
 
 class VoxelGeneratorV2:

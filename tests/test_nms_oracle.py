@@ -1,0 +1,62 @@
+"""CPU: the rotated IoU / NMS oracle (oracle/nms_oracle.py, a restatement of
+second/core/non_max_suppression/nms_gpu.py) against an independent algorithm and known answers.
+The reference's numba-CUDA kernels cannot run here (no numba, no CUDA): parity unpinned against
+the original binaries, see the oracle's header."""
+import math
+
+import numpy as np
+
+from oracle import nms_oracle as O
+
+
+def random_rboxes(rng, n, spread=3.0):
+    c = rng.uniform(-spread, spread, (n, 2))
+    wh = rng.uniform(0.8, 4.5, (n, 2))
+    a = rng.uniform(-math.pi, math.pi, (n, 1))
+    return np.concatenate([c, wh, a], 1).astype(np.float32)
+
+
+def test_known_answers():
+    sq = [0.0, 0.0, 2.0, 2.0, 0.0]
+    assert abs(O.rotate_iou_eval(sq, sq) - 1.0) < 1e-12
+    assert O.rotate_iou_eval(sq, [5.0, 0.0, 2.0, 2.0, 0.3]) == 0.0
+    # unit shift of a 2x2 square: intersection 2, union 6
+    assert abs(O.rotate_iou_eval(sq, [1.0, 0.0, 2.0, 2.0, 0.0]) - 1.0 / 3.0) < 1e-12
+    # the same square turned by 45 degrees: a regular octagon, area 8 (sqrt(2) - 1)
+    oct_area = 8.0 * (math.sqrt(2.0) - 1.0)
+    assert abs(O.inter(sq, [0.0, 0.0, 2.0, 2.0, math.pi / 4]) - oct_area) < 1e-9
+    # a small box inside a big one, any angle: the small area; criteria 0 / 1 / 2
+    big, small = [0.0, 0.0, 10.0, 8.0, 0.4], [0.5, -0.3, 1.0, 2.0, 1.1]
+    assert abs(O.inter(big, small) - 2.0) < 1e-9
+    assert abs(O.rotate_iou_eval(small, big, 0) - 1.0) < 1e-9
+    assert abs(O.rotate_iou_eval(small, big, 1) - 2.0 / 80.0) < 1e-9
+    assert abs(O.rotate_iou_eval(small, big, 2) - 2.0) < 1e-9
+    # axis-aligned with the +1 pixel convention: [0,0,9,9] vs [5,0,14,9]: 5*10 / (200 - 50)
+    assert abs(O.iou_axis_aligned([0, 0, 9, 9], [5, 0, 14, 9]) - 50.0 / 150.0) < 1e-12
+
+
+def test_restatement_matches_polygon_clipping():
+    rng = np.random.default_rng(0)
+    a, b = random_rboxes(rng, 300), random_rboxes(rng, 300)
+    worst = 0.0
+    hits = 0
+    for x, y in zip(a, b):
+        r = O.inter(x, y)
+        s = O.inter_sutherland_hodgman(x, y)
+        worst = max(worst, abs(r - s))
+        hits += r > 0
+    assert hits > 60  # the sample does overlap
+    assert worst < 1e-6
+
+
+def test_nms_known_answer():
+    # three boxes on a line: 0 and 1 overlap heavily, 2 is apart; scores make 1 the survivor
+    dets = np.array([[0, 0, 10, 10, 0.8], [1, 0, 11, 10, 0.9], [30, 0, 40, 10, 0.5]], np.float32)
+    keep, _ = O.nms(dets, 0.5, rotated=False)
+    assert keep == [1, 2]
+    r = np.array([[0, 0, 4, 2, 0.0, 0.7], [0.2, 0, 4, 2, 0.1, 0.9], [0, 5, 4, 2, 1.0, 0.8]],
+                 np.float32)
+    keep, _ = O.nms(r, 0.3, rotated=True)
+    assert keep == [1, 2]
+    keep, _ = O.nms(r, 0.3, rotated=True, max_keep=1)
+    assert keep == [1]
