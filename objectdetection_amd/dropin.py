@@ -12,9 +12,15 @@ import sys
 import types
 
 
-def install(voxel_encoder=False):
+def install(voxel_encoder=False, nms=True):
     """Register ``spconv`` (+ ``spconv.utils``, ``spconv.ops``) and
     ``second.core.point_cloud.point_cloud_ops`` in ``sys.modules``.
+
+    nms=True (default) makes ``second.core.non_max_suppression.nms_gpu`` and ``.nms_cpu`` resolve
+    to ``objectdetection_amd.nms``: the reference's modules are numba-CUDA / numba-jit code and
+    cannot be imported on a ROCm machine (``nms_gpu``, ``rotate_nms_gpu``, ``rotate_iou_gpu``,
+    ``rotate_iou_gpu_eval``, ``nms_gpu_cc``, ``nms_cc``, ``rotate_nms_cc``, ``nms_jit`` are
+    provided; ``soft_nms_jit`` is not).
 
     voxel_encoder=True additionally makes ``second.pytorch.models.voxel_encoder`` resolve to the
     HIP-backed encoders (same class names and registry); leave False to keep the reference's
@@ -46,6 +52,19 @@ def install(voxel_encoder=False):
     sys.modules[pkg_name] = pc
     sys.modules[pkg_name + ".point_cloud_ops"] = point_cloud_ops
     core.point_cloud = pc
+
+    if nms:
+        from . import nms as _nms
+        pkg = types.ModuleType("second.core.non_max_suppression")
+        pkg.__path__ = []
+        for name in ("nms_gpu", "rotate_nms_gpu", "rotate_iou_gpu", "rotate_iou_gpu_eval",
+                     "nms_gpu_cc", "nms_cc", "rotate_nms_cc", "nms_jit"):
+            setattr(pkg, name, getattr(_nms, name))
+        pkg.nms_gpu_module = pkg.nms_cpu_module = _nms
+        sys.modules["second.core.non_max_suppression"] = pkg
+        sys.modules["second.core.non_max_suppression.nms_gpu"] = _nms
+        sys.modules["second.core.non_max_suppression.nms_cpu"] = _nms
+        core.non_max_suppression = pkg
 
     if voxel_encoder:
         from . import voxel_encoder as ve

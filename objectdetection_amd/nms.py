@@ -113,6 +113,22 @@ def rotate_nms_gpu(dets, nms_overlap_thresh, device_id=0):
     return _np_nms(dets, nms_overlap_thresh, 1, 5, False, device_id)
 
 
+def nms_gpu_cc(dets, nms_overlap_thresh, device_id=0):
+    """nms_gpu.py:10-19 (spconv.utils.non_max_suppression on sorted boxes)."""
+    return nms_gpu(dets, nms_overlap_thresh, device_id)
+
+
+def nms_jit(dets, thresh, eps=0.0):
+    """nms_cpu.py:34-67: axis-aligned, `eps` added to widths and heights, overlap >= thresh."""
+    dets = np.asarray(dets, dtype=np.float32)
+    if dets.shape[0] == 0:
+        return []
+    d = torch.from_numpy(dets).to(_dev())
+    order = _order(d[:, 4])
+    keep = nms_sorted(d[order], 0, thresh, eps=eps, inclusive=True)
+    return order[keep].cpu().numpy().astype(np.int32).tolist()
+
+
 def nms_cc(dets, thresh):
     """nms_cpu.py:11-14 (spconv non_max_suppression_cpu, eps = 1, >= threshold)."""
     return _np_nms(dets, thresh, 0, 4, True, 0)

@@ -276,3 +276,21 @@ def test_flat_bucket_clip_equals_clip_grad_norm():
         assert torch.allclose(total, total_ref, rtol=1e-6)
         for p, q in zip(net.parameters(), ref.parameters()):
             assert torch.allclose(p.grad, q.grad, rtol=1e-5, atol=1e-8)
+
+
+def test_dropin_registers_nms_module_names():
+    """second.core.non_max_suppression.{nms_gpu,nms_cpu} (numba-CUDA / numba code in the reference,
+    not importable on ROCm) resolve to objectdetection_amd.nms after dropin.install()."""
+    import objectdetection_amd.dropin as dropin
+    dropin.install()
+    from second.core.non_max_suppression.nms_gpu import (nms_gpu, rotate_iou_gpu,  # noqa: F401
+                                                         rotate_iou_gpu_eval, rotate_nms_gpu)
+    from second.core.non_max_suppression.nms_cpu import nms_cc, rotate_nms_cc  # noqa: F401
+    from second.core.non_max_suppression import nms_jit  # noqa: F401
+    from spconv.utils import rbbox_iou, rotate_non_max_suppression_cpu  # noqa: F401
+    import objectdetection_amd.nms as N
+    assert rotate_nms_gpu is N.rotate_nms_gpu and nms_cc is N.nms_cc
+    import numpy as np
+    assert N.rotate_iou_gpu_eval(np.zeros((0, 5), np.float32), np.zeros((3, 5), np.float32)).shape \
+        == (0, 3)
+    assert N.rotate_nms_gpu(np.zeros((0, 6), np.float32), 0.5) == []
