@@ -402,11 +402,32 @@ class FrameEngine:
             raise ValueError("points must be a [N,4] float32 cuda tensor")
         self.points[:n].copy_(points, non_blocking=True)
         self.n_dev.fill_(n)
+        self.n_points = n
+
+    def forward_append(self, new_points, sync=False):
+        """The light-curtain loop (second/light_curtain/utils.py:121-124 stacks every curtain's
+        return under the cloud and runs the detector again): the cumulative cloud stays in the
+        engine's point buffer, only the NEW points [M,4] f32 cuda are copied behind it, and the
+        frame is re-run.  Same result as forward(torch.cat([previous cloud, new_points]))."""
+        m = int(new_points.shape[0])
+        n0 = getattr(self, "n_points", 0)
+        if n0 + m > self.max_points:
+            raise RuntimeError(f"FrameEngine: {n0 + m} points exceed max_points={self.max_points}")
+        if new_points.shape[1] != self.F or new_points.dtype != torch.float32 \
+                or not new_points.is_cuda:
+            raise ValueError("points must be a [M,4] float32 cuda tensor")
+        self.points[n0:n0 + m].copy_(new_points, non_blocking=True)
+        self.n_points = n0 + m
+        self.n_dev.fill_(self.n_points)
+        return self._run(self.points[:self.n_points], sync)
 
     def forward(self, points, sync=False):
         """points [N,4] f32 cuda -> [1, C*D, H, W] (the engine's static output buffer: consume or
         clone it before the next call).  Nothing here waits for the GPU unless sync=True."""
         self._load(points)
+        return self._run(points, sync)
+
+    def _run(self, points, sync):
         if self.graph is not None:
             self.graph.replay()
         else:
@@ -418,7 +439,7 @@ class FrameEngine:
                 self._plan(None)  # loose capacities; a later calibrate() tightens them again
                 if self.use_graph:
                     self._capture()
-                return self.forward(points, sync=True)
+                return self.forward(points.clone(), sync=True)
         return self.out
 
     __call__ = forward

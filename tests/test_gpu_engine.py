@@ -111,3 +111,24 @@ def test_engine_default_kernel_selection(cuda, name):
             assert err.item() < (1e-5 if name == "M1" else 1e-4)
             again = eng.forward(c)
             assert torch.equal(out, again)  # each path by itself is run-to-run deterministic
+
+
+def test_engine_append_keeps_the_cloud_on_the_device(cuda):
+    """Light-curtain loop: curtain returns are appended to the cloud that already sits in the
+    engine (forward_append copies only the new points); each step equals a fresh forward of the
+    concatenated cloud."""
+    model = randomize_(SparseFrontEnd("M1").eval(), 0).to(cuda)
+    base = _clouds(cuda, [0], 12000)[0]
+    extra = [torch.from_numpy(synth.vkitti_frame(20 + i, 3000)).to(cuda) for i in range(3)]
+    with torch.no_grad(), one_wave_set():
+        eng = model.engine(calib=[torch.cat([base] + extra)], max_points=40000)
+        out = eng.forward(base).clone()
+        assert torch.equal(out, model([base]))
+        cloud = base
+        for e in extra:
+            cloud = torch.cat([cloud, e])
+            out = eng.forward_append(e).clone()
+            eng.check()
+            assert torch.equal(out, model([cloud]))
+        with pytest.raises(RuntimeError):
+            eng.forward_append(torch.zeros((40000, 4), device=cuda))
