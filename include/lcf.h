@@ -181,6 +181,19 @@ int lcf_indice_conv_fwd_bf16(const float *feat, const void *wimg_bf16, const int
                              const int *k_out_dev, int kvol, int cin, int cout,
                              const float *scale, const float *shift, int relu, float *out,
                              void *stream);
+/* fwd with SparseConvTensor.dense() (second/pytorch/models/middle.py:206, right after the last
+ * SparseConv3d + BatchNorm1d + ReLU of the stack, :186-192) fused into its epilogue: instead of
+ * out[row,:] the result lands in dense[b, :, z, y, x] of a [batch, cout, D, H, W] f32 tensor,
+ * (b,z,y,x) = out_coors[row] ([k_out,4] int32, 16-byte aligned; rows with a coordinate outside
+ * the shape are dropped, as lcf_dense drops them).  The caller clears `dense` beforehand.  cout
+ * must be 16, 32, 64 or 128 and nbr non-NULL (LCF_ERR_UNSUPPORTED / LCF_ERR_ARG otherwise: the
+ * caller keeps lcf_indice_conv_fwd + lcf_dense).  Same arithmetic as lcf_indice_conv_fwd:
+ * bit-identical values. */
+int lcf_indice_conv_fwd_dense(const float *feat, const float *wimg, const int *nbr, int k_out,
+                              const int *k_out_dev, int kvol, int cin, int cout,
+                              const float *scale, const float *shift, int relu,
+                              const int *out_coors, int batch, const int shape[3], float *dense,
+                              void *stream);
 int lcf_indice_conv_wgrad(const float *feat, const float *dout, const int *in_nbr, int k_in,
                           int kvol, int cin, int cout, float *dw, void *stream);
 

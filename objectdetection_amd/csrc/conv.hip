@@ -533,6 +533,14 @@ static int cv_launch_ss(const float *feat, const float *wimg, const int *nbr, in
 // Row counts may live on the device (k_dev): the grid is sized by the capacity and workgroups
 // past the actual count exit at once, so the launch needs no host synchronisation.
 
+// Optional dense target of the epilogue (SparseConvTensor.dense() fused into the last conv of the
+// stack): with coors != NULL the tile is written to
+// out[b, c, z, y, x] of a [batch, cout, D, H, W] tensor instead of out[row, c].
+struct TcDense {
+    const int *coors; // [k_out, 4] (b, z, y, x) of the output rows, or NULL
+    int batch, D, H, W;
+};
+
 template <int CIN, int COUT, int TR>
 struct TcCfg {
     static constexpr int NW = (COUT / 16 >= 4) ? 4 : COUT / 16; // waves (column split)
@@ -577,7 +585,8 @@ __global__ void __launch_bounds__(TC_THREADS(COUT) * NSETS)
 cv_tc_kernel(const float *__restrict__ feat, const float *__restrict__ wimg,
              const int *__restrict__ nbr, int k_cap, const int *__restrict__ k_dev, int kvol,
              int cin, int cout, const float *__restrict__ scale,
-             const float *__restrict__ shift, int relu, float *__restrict__ out, int tr)
+             const float *__restrict__ shift, int relu, float *__restrict__ out, int tr,
+             TcDense dn)
 {
     using C = TcCfg<CIN, COUT, TR>;
     constexpr int THREADS = C::THREADS, NT = C::NT, KL = C::KL, VW = C::VW, SG = C::SG;
@@ -912,7 +921,21 @@ cv_tc_kernel(const float *__restrict__ feat, const float *__restrict__ wimg,
                     v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f);
                     v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
                 }
-                *reinterpret_cast<float4 *>(out + (size_t)row * cout + c4 * 4) = v;
+                if (dn.coors) {
+                    const int4 q = reinterpret_cast<const int4 *>(dn.coors)[row];
+                    if (q.x >= 0 && q.x < dn.batch && q.y >= 0 && q.y < dn.D && q.z >= 0 &&
+                        q.z < dn.H && q.w >= 0 && q.w < dn.W) {
+                        const size_t svol = (size_t)dn.D * dn.H * dn.W;
+                        float *d = out + ((size_t)q.x * cout + c4 * 4) * svol +
+                                   ((size_t)q.y * dn.H + q.z) * dn.W + q.w;
+                        d[0] = v.x;
+                        d[svol] = v.y;
+                        d[2 * svol] = v.z;
+                        d[3 * svol] = v.w;
+                    }
+                } else {
+                    *reinterpret_cast<float4 *>(out + (size_t)row * cout + c4 * 4) = v;
+                }
             }
         }
     } else {
@@ -938,7 +961,8 @@ static int g_rows_hint = 0; // LCF_OPT_CONV_ROWS_HINT: expected rows (0 = the ca
 template <int CIN, int COUT, int TR, bool BF16 = false, int NSETS = 1>
 static int cv_launch_tc_n(const float *feat, const float *wimg, const int *nbr, int k_cap,
                           const int *k_dev, int kvol, int cin, int cout, const float *scale,
-                          const float *shift, int relu, float *out, hipStream_t st, int tr = TR)
+                          const float *shift, int relu, float *out, hipStream_t st, int tr = TR,
+                          TcDense dn = TcDense{nullptr, 0, 0, 0, 0})
 {
     using C = TcCfg<CIN, COUT, TR>;
     size_t lds = tc_lds_bytes(CIN, COUT, TR, kvol, BF16, NSETS);
@@ -958,18 +982,19 @@ static int cv_launch_tc_n(const float *feat, const float *wimg, const int *nbr, 
         lds_set = lds;
     }
     if (tr < 1 || tr > TR) return LCF_ERR_ARG;
+    if (dn.coors && (cout != COUT || BF16)) return LCF_ERR_UNSUPPORTED;
     int nb = (k_cap + tr - 1) / tr;
     constexpr int TT = C::THREADS * NSETS;
     if constexpr (BF16) {
         if (cin != CIN) return LCF_ERR_UNSUPPORTED;
         cv_tc_kernel<CIN, COUT, TR, true, true, NSETS><<<nb, TT, lds, st>>>(
-            feat, wimg, nbr, k_cap, k_dev, kvol, cin, cout, scale, shift, relu, out, tr);
+            feat, wimg, nbr, k_cap, k_dev, kvol, cin, cout, scale, shift, relu, out, tr, dn);
     } else if (cin == CIN)
         cv_tc_kernel<CIN, COUT, TR, true, false, NSETS><<<nb, TT, lds, st>>>(
-            feat, wimg, nbr, k_cap, k_dev, kvol, cin, cout, scale, shift, relu, out, tr);
+            feat, wimg, nbr, k_cap, k_dev, kvol, cin, cout, scale, shift, relu, out, tr, dn);
     else
         cv_tc_kernel<CIN, COUT, TR, false, false, NSETS><<<nb, TT, lds, st>>>(
-            feat, wimg, nbr, k_cap, k_dev, kvol, cin, cout, scale, shift, relu, out, tr);
+            feat, wimg, nbr, k_cap, k_dev, kvol, cin, cout, scale, shift, relu, out, tr, dn);
     LCF_CHECK_LAUNCH();
     return LCF_OK;
 }
@@ -1004,7 +1029,8 @@ static bool tc_two_sets_fit(int CIN, int COUT, int kvol, int rows, int tr)
 template <int CIN, int COUT>
 static int cv_launch_tc(const float *feat, const float *wimg, const int *nbr, int k_cap,
                         const int *k_dev, int kvol, int cin, int cout, const float *scale,
-                        const float *shift, int relu, float *out, hipStream_t st)
+                        const float *shift, int relu, float *out, hipStream_t st,
+                        TcDense dn = TcDense{nullptr, 0, 0, 0, 0})
 {
     // tiles of up to 32 rows: measured against 64-row tiles on every SECOND layer (half the
     // workgroups with the same serial chain lose)
@@ -1013,9 +1039,9 @@ static int cv_launch_tc(const float *feat, const float *wimg, const int *nbr, in
     const bool two = g_tc_sets == 2 || (g_tc_sets == 0 && tc_two_sets_fit(CIN, COUT, kvol, rows, tr));
     if (two && tc_lds_bytes(CIN, COUT, 32, kvol, false, 2) <= 160 * 1024)
         return cv_launch_tc_n<CIN, COUT, 32, false, 2>(feat, wimg, nbr, k_cap, k_dev, kvol, cin,
-                                                       cout, scale, shift, relu, out, st, tr);
+                                                       cout, scale, shift, relu, out, st, tr, dn);
     return cv_launch_tc_n<CIN, COUT, 32>(feat, wimg, nbr, k_cap, k_dev, kvol, cin, cout, scale,
-                                         shift, relu, out, st, tr);
+                                         shift, relu, out, st, tr, dn);
 }
 
 // -------------------------------------------------------------------------- bf16 entry points
@@ -1417,6 +1443,28 @@ extern "C" int lcf_indice_conv_fwd(const float *feat, const float *wimg, const i
     }
     CV_DISPATCH(cv_launch_tc, feat, wimg, nbr, k_out, k_out_dev, kvol, cin, cout, scale, shift,
                 relu, out, st);
+}
+
+extern "C" int lcf_indice_conv_fwd_dense(const float *feat, const float *wimg, const int *nbr,
+                                         int k_out, const int *k_out_dev, int kvol, int cin,
+                                         int cout, const float *scale, const float *shift,
+                                         int relu, const int *out_coors, int batch,
+                                         const int shape[3], float *dense, void *stream)
+{
+    if (k_out < 0 || kvol <= 0 || cin <= 0 || cout <= 0 || !wimg || !nbr || !shape ||
+        batch <= 0 || (k_out > 0 && (!feat || !dense || !out_coors)))
+        return LCF_ERR_ARG;
+    if (kvol > LCF_MAX_KVOL) return LCF_ERR_UNSUPPORTED;
+    if (((uintptr_t)feat & 15) || ((uintptr_t)wimg & 15) || ((uintptr_t)out_coors & 15) ||
+        ((uintptr_t)scale & 15) || ((uintptr_t)shift & 15))
+        return LCF_ERR_ARG;
+    if (k_out >= (1 << 26)) return LCF_ERR_RANGE;
+    int CIN = cv_pad_cin(cin), COUT = cv_pad_cout(cout);
+    if (CIN < 0 || COUT < 0 || COUT != cout) return LCF_ERR_UNSUPPORTED;
+    if (k_out == 0) return LCF_OK;
+    const TcDense dn{out_coors, batch, shape[0], shape[1], shape[2]};
+    CV_DISPATCH(cv_launch_tc, feat, wimg, nbr, k_out, k_out_dev, kvol, cin, cout, scale, shift,
+                relu, dense, (hipStream_t)stream, dn);
 }
 
 template <int CIN, int COUT>

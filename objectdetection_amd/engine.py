@@ -57,6 +57,8 @@ class FrameEngine:
         self.L = _lib.lib()
         self.use_graph = use_graph
         self.two_streams = bool(two_streams)
+        # dense() fused into the last conv's epilogue (lcf_indice_conv_fwd_dense)
+        self.fuse_dense = os.environ.get("LCF_ENGINE_FUSE_DENSE", "1") != "0"
         self.side = torch.cuda.Stream(device=self.dev) if self.two_streams else None
         self.margin = float(margin)
         vg = model.voxel_generator
@@ -367,17 +369,28 @@ class FrameEngine:
             # the launch is sized by the capacity; the kernel variant by the rows expected
             need = self.level_need
             L.lcf_set_option(_lib.OPT_CONV_ROWS_HINT, int(need[lvl]) if need else 0)
+            if not l.subm:
+                coors, kd = l.out_coors, l.k_out
+            if l is self.layers[-1] and self.fuse_dense and l.cout in (16, 32, 64, 128):
+                # dense() in the epilogue of the last conv: its rows go straight to [1,C,D,H,W]
+                if self.two_streams:
+                    main.wait_event(e_dense)
+                check(L.lcf_indice_conv_fwd_dense(
+                    P(feat), P(l.wimg), P(o.nbr), k_out_cap, P(k_out_dev), l.kvol, l.cin, l.cout,
+                    P(l.scale), P(l.shift), int(l.relu), P(coors), 1, i3(self.out_shape),
+                    P(self.dense), st))
+                feat = None
+                break
             check(L.lcf_indice_conv_fwd(P(feat), P(l.wimg), P(o.nbr), k_out_cap, P(k_out_dev),
                                         l.kvol, l.cin, l.cout, P(l.scale), P(l.shift),
                                         int(l.relu), P(l.out), st))
             feat = l.out
-            if not l.subm:
-                coors, kd = l.out_coors, l.k_out
         L.lcf_set_option(_lib.OPT_CONV_ROWS_HINT, 0)
-        if self.two_streams:
-            main.wait_event(e_dense)
-        check(L.lcf_dense(P(feat), P(coors), feat.shape[0], P(kd), feat.shape[1], 1,
-                          i3(self.out_shape), 0, P(self.dense), st))
+        if feat is not None:
+            if self.two_streams:
+                main.wait_event(e_dense)
+            check(L.lcf_dense(P(feat), P(coors), feat.shape[0], P(kd), feat.shape[1], 1,
+                              i3(self.out_shape), 0, P(self.dense), st))
         if self.two_streams:
             main.wait_event(e_side)  # joins the side stream (its last operation)
 

@@ -298,6 +298,22 @@ def conv_forward(features, wimg, nbr, n_rows, kvol, cin, cout, scale=None, shift
     return out
 
 
+def conv_forward_dense(features, wimg, nbr, n_rows, kvol, cin, cout, out_coors, batch_size,
+                       shape, scale=None, shift=None, relu=False, n_rows_dev=None, out=None):
+    """conv_forward whose rows land in a dense [batch, cout, D, H, W] tensor at ``out_coors``
+    ([n_rows,4] int32 b,z,y,x): conv + SparseConvTensor.dense() in one kernel
+    (lcf_indice_conv_fwd_dense).  ``out``, when given, must already be cleared."""
+    _need_cuda(features, wimg, nbr, out_coors)
+    x = features.contiguous()
+    if out is None:
+        out = torch.zeros((int(batch_size), cout, *shape), dtype=torch.float32, device=x.device)
+    check(_lib.lib().lcf_indice_conv_fwd_dense(
+        _ptr(x), _ptr(wimg), _ptr(nbr), int(n_rows), _ptr(n_rows_dev), int(kvol), int(cin),
+        int(cout), _ptr(scale), _ptr(shift), int(bool(relu)), _ptr(out_coors.contiguous()),
+        int(batch_size), i3(shape), _ptr(out), _stream()))
+    return out
+
+
 def conv_wgrad(features, dout, in_nbr, kvol, cin, cout):
     x = features.contiguous()
     g = dout.contiguous()

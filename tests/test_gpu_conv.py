@@ -1,4 +1,6 @@
 """GPU parity: indice_conv forward / dgrad / wgrad, dense, VFE kernels vs the CPU oracle."""
+import ctypes
+
 import numpy as np
 import pytest
 import torch
@@ -164,6 +166,80 @@ def test_tile_compacted_variants_match_oracle(oracle, cuda, cin, cout, sets, til
         L.lcf_set_option(_lib.OPT_CONV_TILE, 0)
     assert rel_err(out.cpu().numpy(), ref) < RTOL
     assert torch.equal(out, again)
+
+
+@pytest.mark.parametrize("cin,cout,sets", [(64, 64, 1), (64, 64, 2), (16, 16, 1), (32, 128, 2),
+                                           (128, 32, 1), (5, 64, 1)])
+def test_conv_with_dense_epilogue_equals_conv_then_dense(oracle, cuda, cin, cout, sets):
+    """lcf_indice_conv_fwd_dense (the stack's last SparseConv3d (3,1,1)/(2,1,1) + BN + ReLU with
+    .dense() fused, middle.py:186-206) == lcf_indice_conv_fwd followed by lcf_dense, bit for bit,
+    and == the oracle's conv + dense within the fp32 tolerance; batch of two scenes, a device-side
+    row count below the capacity, and rows outside the dense shape dropped."""
+    from objectdetection_amd import _lib
+    rng = np.random.default_rng(cin * 3 + cout + sets)
+    cs = []
+    for b in range(2):
+        c = _frame_coors(oracle, 11 + b, 9000)
+        c[:, 1:] //= 8
+        c[:, 0] = b
+        cs.append(np.unique(c, axis=0))
+    coors = np.concatenate(cs, 0).astype(np.int32)
+    rng.shuffle(coors, axis=0)
+    coors = np.ascontiguousarray(coors)
+    shape = [5, 200, 176]
+    k = coors.shape[0]
+    x = rng.standard_normal((k, cin)).astype(np.float32)
+    w = (rng.standard_normal((3, 1, 1, cin, cout)) / np.sqrt(3 * cin)).astype(np.float32)
+    sc = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+    sh = rng.standard_normal(cout).astype(np.float32)
+    oc, pairs, pn, oshape = oracle.rulebook_conv(coors, 2, shape, [3, 1, 1], [2, 1, 1], 0)
+    assert list(oshape) == [2, 200, 176]
+    ref = np.maximum(oracle.indice_conv_fwd(x, w, pairs, pn, oc.shape[0]) * sc[None] + sh[None], 0)
+    ref_dense = oracle.dense(ref, oc, 2, oshape)
+    rb = ops.build_rulebook(torch.from_numpy(coors).to(cuda), 2, shape, [3, 1, 1], [2, 1, 1], 0,
+                            1, False)
+    assert rb.k_out == oc.shape[0]
+    xt, wt = torch.from_numpy(x).to(cuda), torch.from_numpy(w).to(cuda)
+    sct, sht = torch.from_numpy(sc).to(cuda), torch.from_numpy(sh).to(cuda)
+    wimg = ops.weight_image(wt)
+    L = _lib.lib()
+    try:
+        assert L.lcf_set_option(_lib.OPT_CONV_IMPL, 2) == 0
+        assert L.lcf_set_option(_lib.OPT_CONV_SETS, sets) == 0
+        rows = ops.conv_forward(xt, wimg, rb.out_nbr, rb.k_out, 3, cin, cout, sct, sht, True)
+        two = ops.dense(rows, rb.out_indices, 2, oshape)
+        one = ops.conv_forward_dense(xt, wimg, rb.out_nbr, rb.k_out, 3, cin, cout,
+                                     rb.out_indices, 2, oshape, sct, sht, True)
+        assert torch.equal(one, two)
+        assert rel_err(one.cpu().numpy(), ref_dense) < RTOL
+        # capacity > device-side count: rows past the count are not written
+        cnt = rb.k_out - 37
+        kd = torch.tensor([cnt], dtype=torch.int32, device=cuda)
+        part = ops.conv_forward_dense(xt, wimg, rb.out_nbr, rb.k_out, 3, cin, cout,
+                                      rb.out_indices, 2, oshape, sct, sht, True, n_rows_dev=kd)
+        assert torch.equal(part, ops.dense(rows[:cnt], rb.out_indices[:cnt], 2, oshape))
+        # a smaller dense shape: rows outside are dropped (as lcf_dense drops them)
+        small = [2, 150, 100]
+        crop = ops.conv_forward_dense(xt, wimg, rb.out_nbr, rb.k_out, 3, cin, cout,
+                                      rb.out_indices, 1, small, sct, sht, True)
+        assert torch.equal(crop, ops.dense(rows, rb.out_indices, 1, small))
+        assert torch.equal(crop[0], two[0, :, :, :150, :100])
+    finally:
+        L.lcf_set_option(_lib.OPT_CONV_IMPL, 0)
+        L.lcf_set_option(_lib.OPT_CONV_SETS, 0)
+
+
+def test_conv_with_dense_epilogue_rejects_what_it_cannot_do(cuda):
+    from objectdetection_amd import _lib
+    L = _lib.lib()
+    t = torch.zeros(4096, device=cuda)
+    i = torch.zeros(4096, dtype=torch.int32, device=cuda)
+    a = lambda cout, nbr: L.lcf_indice_conv_fwd_dense(
+        t.data_ptr(), t.data_ptr(), nbr, 8, None, 3, 16, cout, None, None, 0, i.data_ptr(), 1,
+        (ctypes.c_int * 3)(1, 2, 4), t.data_ptr(), None)
+    assert a(24, i.data_ptr()) == -3  # LCF_ERR_UNSUPPORTED: padded output width
+    assert a(16, None) == -1  # LCF_ERR_ARG: no neighbour table
+    torch.cuda.synchronize()
 
 
 def test_option_values_are_validated(cuda):
