@@ -149,6 +149,11 @@ def main():
     ap.add_argument("--train-batch", type=int, default=8, help="frames per rank per step")
     ap.add_argument("--inflight", type=int, default=1,
                     help="independent frames in flight (one FrameEngine + stream each)")
+    ap.add_argument("--conv-math", default="f32", choices=["f32", "bf16x3"],
+                    help="operand form of the 32/64/128-channel sparse convs in the timed path: "
+                         "fp32 MFMA (the headline) or split bf16 operands (lcf.h: bf16x3)")
+    ap.add_argument("--no-alt", action="store_true",
+                    help="skip the secondary bf16x3 measurement reported beside the headline")
     ap.add_argument("--eager", action="store_true",
                     help="module-by-module path (spconv API, host syncs) instead of the "
                          "graph-captured FrameEngine")
@@ -192,13 +197,14 @@ def main():
             step = lambda c: model([c])
         else:
             # one hipGraph replay per frame; capacities calibrated on this rank's frames
-            engine = model.engine(calib=clouds)
+            engine = model.engine(calib=clouds, conv_math=args.conv_math)
             step = engine.forward
             if args.inflight > 1:
                 # serving with several batch-1 requests in flight: one engine (own buffers, own
                 # graph) per slot, each on its own stream; frames alternate over the slots
                 streams = [torch.cuda.Stream(device=dev) for _ in range(args.inflight)]
-                engines = [engine] + [model.engine(calib=clouds) for _ in range(args.inflight - 1)]
+                engines = [engine] + [model.engine(calib=clouds, conv_math=args.conv_math)
+                                      for _ in range(args.inflight - 1)]
                 slot = [0]
 
                 def step(c):
@@ -230,6 +236,26 @@ def main():
         assert out.shape[1:] == (128, 200, 176) or args.model == "M3", out.shape
         roof = dominant_kernel_roofline(model, clouds[0]) if rank == 0 and args.model != "M3" \
             else None
+        # secondary line (never `value`): the same frames through an engine whose wide sparse
+        # convs run split-operand bf16x3 math, with its error against the fp32 module path
+        alt = None
+        if (world == 1 and not args.eager and not args.no_alt and args.conv_math == "f32"
+                and args.model != "M3"):
+            eng3 = model.engine(calib=clouds, conv_math="bf16x3")
+            for i in range(args.warmup):
+                eng3.forward(clouds[i % len(clouds)])
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for i in range(args.steps):
+                out3 = eng3.forward(clouds[i % len(clouds)])
+            torch.cuda.synchronize()
+            el3 = time.perf_counter() - t1
+            eng3.check()
+            err3 = ((out3 - ref).abs().max() / ref.abs().max()).item()
+            assert err3 < 1e-4, f"bf16x3 engine outside the fp32 feature tolerance: {err3}"
+            alt = {"conv_math": "bf16x3", "value": round(args.steps / el3, 2),
+                   "unit": "frames/s", "ms_per_step": round(el3 / args.steps * 1e3, 4),
+                   "max_err_vs_f32_rel_to_max": float(f"{err3:.3g}"), "tolerance": 1e-4}
 
     train = train_measurement(args, dev, rank, world, dist, barrier) if args.train_steps > 0 \
         and args.model != "M3" else None
@@ -240,7 +266,8 @@ def main():
             "metric": "frames/s voxelize+sparse backbone fwd (bs1)",
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if args.conv_math == "f32" else "bf16x3 (f32 = hi + lo, f32 accumulate)",
             "data": "synthetic",
             "config": {"workload": f"{args.model}: one {args.points}-point "
                                    f"{'Virtual-KITTI' if args.shape == 'vkitti' else 'SYNTHIA'}-shaped "
@@ -255,6 +282,8 @@ def main():
         }
         if roof is not None:
             line["roofline"] = roof
+        if alt is not None:
+            line["alt"] = alt
         if train is not None:
             line["train"] = train
         if world == 1 and not args.no_cpu_baseline:

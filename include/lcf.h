@@ -181,6 +181,24 @@ int lcf_indice_conv_fwd_bf16(const float *feat, const void *wimg_bf16, const int
                              const int *k_out_dev, int kvol, int cin, int cout,
                              const float *scale, const float *shift, int relu, float *out,
                              void *stream);
+/* Split-operand variant ("bf16x3") of the fp32 forward, for inference at fp32 tolerance on the
+ * bf16 matrix cores: every fp32 operand is x = hi + lo, hi = bf16(x), lo = bf16(x - hi)
+ * (|x - hi - lo| <= 2^-18 |x|); features are split when they enter LDS, the weights come as a
+ * two-plane bf16 image (lcf_weight_image_bf16x3: 2 * kvol*cin*cout 2-byte elements, as many
+ * bytes as the fp32 image), and each product is lo_a*hi_w + hi_a*lo_w + hi_a*hi_w with fp32
+ * accumulation.  Error per product <= 3 * 2^-18 |a||w| (1.1e-5; measured on the network's
+ * features: <= 1e-5 of the tensor's max magnitude against the float64-accumulating oracle, the
+ * north star's bound is 1e-4).  cin, cout in {32, 64, 128} (LCF_ERR_UNSUPPORTED otherwise: the
+ * caller keeps lcf_indice_conv_fwd).  dense_coors != NULL: `out` is the cleared dense
+ * [batch, cout, D, H, W] tensor of lcf_indice_conv_fwd_dense; NULL: out [k_out, cout], and
+ * batch / shape are ignored.  No counterpart in the reference (its spconv runs fp32 GEMMs). */
+int lcf_weight_image_bf16x3(const float *w, int kvol, int cin, int cout, int transpose,
+                            void *img, void *stream);
+int lcf_indice_conv_fwd_bf16x3(const float *feat, const void *wimg_bf16x3, const int *nbr,
+                               int k_out, const int *k_out_dev, int kvol, int cin, int cout,
+                               const float *scale, const float *shift, int relu, float *out,
+                               const int *dense_coors, int batch, const int shape[3],
+                               void *stream);
 /* fwd with SparseConvTensor.dense() (second/pytorch/models/middle.py:206, right after the last
  * SparseConv3d + BatchNorm1d + ReLU of the stack, :186-192) fused into its epilogue: instead of
  * out[row,:] the result lands in dense[b, :, z, y, x] of a [batch, cout, D, H, W] f32 tensor,

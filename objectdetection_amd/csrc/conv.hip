@@ -560,10 +560,11 @@ struct TcCfg {
 
 static size_t tc_max(size_t a, size_t b) { return a > b ? a : b; }
 
-static size_t tc_lds_bytes(int CIN, int COUT, int TR, int kvol, bool bf16 = false, int nsets = 1)
+static size_t tc_lds_bytes(int CIN, int COUT, int TR, int kvol, bool bf16 = false, int nsets = 1,
+                           int planes = 1)
 {
     const int abufs = nsets == 1 ? 2 : 1; // one wave set double-buffers its rows, two do not
-    size_t b = bf16 ? (size_t)nsets * abufs * TR * (CIN + 8) * 2          // A rows, bf16
+    size_t b = bf16 ? (size_t)nsets * abufs * planes * TR * (CIN + 8) * 2 // A rows, bf16
                     : (size_t)nsets * abufs * TR * (CIN + 4) * 4;         // A rows of one offset
     b += tc_max((size_t)nsets * (TR + 1) * (COUT + 4) * 4, (size_t)TR * kvol * 4); // tiles | nbr
     b = (b + 15) & ~(size_t)15;
@@ -577,10 +578,16 @@ static size_t tc_lds_bytes(int CIN, int COUT, int TR, int kvol, bool bf16 = fals
 // BF16: operands rounded to bf16 (features when they enter LDS, weights in a bf16 image in
 // v_mfma_f32_16x16x32_bf16 fragment order), fp32 accumulation and fp32 output: the training
 // variant BASELINE.json configs[2] names.  Needs Cin a multiple of 32.
+// NP = 2 (with BF16): fp32 operands split into two bf16 planes, x = hi + lo with hi = bf16(x),
+// lo = bf16(x - hi) (|x - hi - lo| <= 2^-18 |x|), and the product taken as
+// lo_a*hi_w + hi_a*lo_w + hi_a*hi_w on the bf16 matrix cores with fp32 accumulation: three
+// v_mfma_f32_16x16x32_bf16 (48 cycles) where fp32 operands need eight v_mfma_f32_16x16x4_f32
+// (256 cycles), and unlike those they overlap the loop's vector instructions.  Dropped terms are
+// <= 3 * 2^-18 of |a||w| per product (1.1e-5; fp32 products: 6e-8).
 // NSETS = 2: a second set of waves takes every other step (offset), with its own row buffer and
 // its own output tile; the two tiles are summed (set 0 + set 1) in the epilogue.  Halves the
 // serial chain of a tile, which is what bounds layers with few tiles per CU.
-template <int CIN, int COUT, int TR, bool EXACT, bool BF16, int NSETS>
+template <int CIN, int COUT, int TR, bool EXACT, bool BF16, int NSETS, int NP>
 __global__ void __launch_bounds__(TC_THREADS(COUT) * NSETS)
 cv_tc_kernel(const float *__restrict__ feat, const float *__restrict__ wimg,
              const int *__restrict__ nbr, int k_cap, const int *__restrict__ k_dev, int kvol,
@@ -608,7 +615,8 @@ cv_tc_kernel(const float *__restrict__ feat, const float *__restrict__ wimg,
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int ASTRH = CIN + 8;                               // bf16 A row stride (halfs)
     constexpr int KS = CIN >= 32 ? CIN / 32 : 1;                 // bf16 k-steps of 32
-    constexpr size_t ABYTES = BF16 ? (size_t)NSETS * ABUFS * TR * ASTRH * 2
+    constexpr int APL = TR * ASTRH;                              // halfs of one bf16 plane
+    constexpr size_t ABYTES = BF16 ? (size_t)NSETS * ABUFS * NP * APL * 2
                                    : (size_t)NSETS * ABUFS * TR * ASTR * 4;
     float *ot0 = reinterpret_cast<float *>(smem + ABYTES);       // [NSETS][TR + dump row][OSTR]
     int *nl = reinterpret_cast<int *>(ot0);                      // [TR][kvol], dead before ot lives
@@ -630,7 +638,7 @@ cv_tc_kernel(const float *__restrict__ feat, const float *__restrict__ wimg,
     const int r16 = lane & 15;
     const int q = lane >> 4;
     float *al = reinterpret_cast<float *>(smem) + set * ABUFS * TR * ASTR;    // [ABUFS][TR][ASTR]
-    __bf16 *alh = reinterpret_cast<__bf16 *>(smem) + set * ABUFS * TR * ASTRH; // bf16 form
+    __bf16 *alh = reinterpret_cast<__bf16 *>(smem) + set * ABUFS * NP * APL; // [ABUFS][NP][TR][ASTRH]
     float *ot = ot0 + set * OTE;                                 // this set's output tile
 
     // ---- neighbour tile -> LDS (coalesced; rows past k_out read as -1)
@@ -693,7 +701,7 @@ cv_tc_kernel(const float *__restrict__ feat, const float *__restrict__ wimg,
     struct AReg { float4 v[MAXG][APT]; };
     struct BReg {
         float b[NT][BF16 ? 1 : KL];
-        bf16x8 h[NT][BF16 ? KS : 1];
+        bf16x8 h[NT][BF16 ? KS * NP : 1]; // [ks * NP + plane]
     };
 
     // rows of the ng groups starting at item i0: thread -> (row r of a group, 16-byte chunk cc)
@@ -725,7 +733,7 @@ cv_tc_kernel(const float *__restrict__ feat, const float *__restrict__ wimg,
     };
     auto astore = [&](int buf, const AReg &a, int ng) {
         float *dst = al + buf * TR * ASTR;
-        __bf16 *dsth = alh + buf * TR * ASTRH;
+        __bf16 *dsth = alh + buf * NP * APL;
 #pragma unroll
         for (int g = 0; g < MAXG; ++g) {
 #pragma unroll
@@ -737,6 +745,12 @@ cv_tc_kernel(const float *__restrict__ feat, const float *__restrict__ wimg,
                         const float4 v = a.v[g][x];
                         bf16x4 h = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
                         *reinterpret_cast<bf16x4 *>(dsth + (g * 16 + r) * ASTRH + cc * 4) = h;
+                        if constexpr (NP == 2) {
+                            bf16x4 l = {(__bf16)(v.x - (float)h[0]), (__bf16)(v.y - (float)h[1]),
+                                        (__bf16)(v.z - (float)h[2]), (__bf16)(v.w - (float)h[3])};
+                            *reinterpret_cast<bf16x4 *>(dsth + APL + (g * 16 + r) * ASTRH +
+                                                        cc * 4) = l;
+                        }
                     } else {
                         *reinterpret_cast<float4 *>(dst + (g * 16 + r) * ASTR + cc * 4) =
                             a.v[g][x];
@@ -749,15 +763,18 @@ cv_tc_kernel(const float *__restrict__ feat, const float *__restrict__ wimg,
     auto bload = [&](int o) -> BReg {
         BReg w;
         if constexpr (BF16) {
-            // image [o][tg][ks][q][r16][8]: lane (q, r16) holds B[k = 32ks + 8q + j][col]
+            // image [plane][o][tg][ks][q][r16][8]: lane (q, r16) holds B[k = 32ks + 8q + j][col]
             const __bf16 *wo = reinterpret_cast<const __bf16 *>(wimg) + (size_t)o * WELEMS;
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 const int tg = wave * NT + t;
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks)
-                    w.h[t][ks] = *reinterpret_cast<const bf16x8 *>(
-                        wo + (((tg * KS + ks) * 4 + q) * 16 + r16) * 8);
+#pragma unroll
+                    for (int pl = 0; pl < NP; ++pl)
+                        w.h[t][ks * NP + pl] = *reinterpret_cast<const bf16x8 *>(
+                            wo + (size_t)pl * kvol * WELEMS +
+                            (((tg * KS + ks) * 4 + q) * 16 + r16) * 8);
             }
             return w;
         }
@@ -789,13 +806,15 @@ cv_tc_kernel(const float *__restrict__ feat, const float *__restrict__ wimg,
     auto compute = [&](int abuf, int g, const BReg &w, int i) {
         const float *ap = al + (abuf * TR + g * 16 + r16) * ASTR + q * KL;
         float a[KL];
-        bf16x8 ah[KS];
+        bf16x8 ah[KS * NP];
         if constexpr (BF16) {
             // lane (r16, q) holds A[row r16][k = 32ks + 8q + j]
-            const __bf16 *aph = alh + (abuf * TR + g * 16 + r16) * ASTRH + q * 8;
+            const __bf16 *aph = alh + abuf * NP * APL + (g * 16 + r16) * ASTRH + q * 8;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks)
-                ah[ks] = *reinterpret_cast<const bf16x8 *>(aph + ks * 32);
+#pragma unroll
+                for (int pl = 0; pl < NP; ++pl)
+                    ah[ks * NP + pl] = *reinterpret_cast<const bf16x8 *>(aph + pl * APL + ks * 32);
         } else if constexpr (KL >= 4) {
 #pragma unroll
             for (int j = 0; j < KL / 4; ++j) {
@@ -826,9 +845,16 @@ cv_tc_kernel(const float *__restrict__ feat, const float *__restrict__ wimg,
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-                for (int t = 0; t < NT; ++t)
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[ks], w.h[t][ks], acc[t],
-                                                                     0, 0, 0);
+                for (int t = 0; t < NT; ++t) {
+                    if constexpr (NP == 2) { // lo*hi + hi*lo, then hi*hi
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                            ah[ks * 2 + 1], w.h[t][ks * 2], acc[t], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                            ah[ks * 2], w.h[t][ks * 2 + 1], acc[t], 0, 0, 0);
+                    }
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[ks * NP], w.h[t][ks * NP],
+                                                                     acc[t], 0, 0, 0);
+                }
         } else {
 #pragma unroll
             for (int s = 0; s < KL; ++s)
@@ -958,23 +984,24 @@ static int g_tc_rows = 0; // LCF_OPT_CONV_TILE: 0 = balance over the CUs, 16..32
 static int g_tc_sets = 0; // LCF_OPT_CONV_SETS: 0 = choose from the row count, 1 or 2 wave sets
 static int g_rows_hint = 0; // LCF_OPT_CONV_ROWS_HINT: expected rows (0 = the capacity passed)
 
-template <int CIN, int COUT, int TR, bool BF16 = false, int NSETS = 1>
+template <int CIN, int COUT, int TR, bool BF16 = false, int NSETS = 1, int NP = 1>
 static int cv_launch_tc_n(const float *feat, const float *wimg, const int *nbr, int k_cap,
                           const int *k_dev, int kvol, int cin, int cout, const float *scale,
                           const float *shift, int relu, float *out, hipStream_t st, int tr = TR,
                           TcDense dn = TcDense{nullptr, 0, 0, 0, 0})
 {
     using C = TcCfg<CIN, COUT, TR>;
-    size_t lds = tc_lds_bytes(CIN, COUT, TR, kvol, BF16, NSETS);
+    static_assert(NP == 1 || BF16, "operand planes are a bf16 notion");
+    size_t lds = tc_lds_bytes(CIN, COUT, TR, kvol, BF16, NSETS, NP);
     if (lds > 160 * 1024) return LCF_ERR_UNSUPPORTED;
     static size_t lds_set = 0; // per instantiation: largest dynamic LDS size opted into so far
     if (lds > 64 * 1024 && lds > lds_set) {
-        if (hipFuncSetAttribute((const void *)cv_tc_kernel<CIN, COUT, TR, true, BF16, NSETS>,
+        if (hipFuncSetAttribute((const void *)cv_tc_kernel<CIN, COUT, TR, true, BF16, NSETS, NP>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds) != hipSuccess)
             return LCF_ERR_LAUNCH;
         if constexpr (!BF16) {
-            if (hipFuncSetAttribute((const void *)cv_tc_kernel<CIN, COUT, TR, false, false, NSETS>,
+            if (hipFuncSetAttribute((const void *)cv_tc_kernel<CIN, COUT, TR, false, false, NSETS, 1>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)lds) != hipSuccess)
                 return LCF_ERR_LAUNCH;
@@ -982,18 +1009,18 @@ static int cv_launch_tc_n(const float *feat, const float *wimg, const int *nbr, 
         lds_set = lds;
     }
     if (tr < 1 || tr > TR) return LCF_ERR_ARG;
-    if (dn.coors && (cout != COUT || BF16)) return LCF_ERR_UNSUPPORTED;
+    if (dn.coors && cout != COUT) return LCF_ERR_UNSUPPORTED;
     int nb = (k_cap + tr - 1) / tr;
     constexpr int TT = C::THREADS * NSETS;
     if constexpr (BF16) {
         if (cin != CIN) return LCF_ERR_UNSUPPORTED;
-        cv_tc_kernel<CIN, COUT, TR, true, true, NSETS><<<nb, TT, lds, st>>>(
+        cv_tc_kernel<CIN, COUT, TR, true, true, NSETS, NP><<<nb, TT, lds, st>>>(
             feat, wimg, nbr, k_cap, k_dev, kvol, cin, cout, scale, shift, relu, out, tr, dn);
     } else if (cin == CIN)
-        cv_tc_kernel<CIN, COUT, TR, true, false, NSETS><<<nb, TT, lds, st>>>(
+        cv_tc_kernel<CIN, COUT, TR, true, false, NSETS, 1><<<nb, TT, lds, st>>>(
             feat, wimg, nbr, k_cap, k_dev, kvol, cin, cout, scale, shift, relu, out, tr, dn);
     else
-        cv_tc_kernel<CIN, COUT, TR, false, false, NSETS><<<nb, TT, lds, st>>>(
+        cv_tc_kernel<CIN, COUT, TR, false, false, NSETS, 1><<<nb, TT, lds, st>>>(
             feat, wimg, nbr, k_cap, k_dev, kvol, cin, cout, scale, shift, relu, out, tr, dn);
     LCF_CHECK_LAUNCH();
     return LCF_OK;
@@ -1017,10 +1044,11 @@ static int tc_tile_rows(int rows)
 // Two wave sets pay when every tile of the launch is resident at once (the chain of a tile, not
 // the number of slots, is then what bounds the launch): workgroups per CU by LDS and by waves
 // (6 per SIMD at this register count) x 256 CUs against the number of tiles.
-static bool tc_two_sets_fit(int CIN, int COUT, int kvol, int rows, int tr)
+static bool tc_two_sets_fit(int CIN, int COUT, int kvol, int rows, int tr, bool bf16 = false,
+                            int planes = 1)
 {
     const int nw = (COUT / 16 >= 4 ? 4 : COUT / 16) * 2;
-    const size_t lds = tc_lds_bytes(CIN, COUT, 32, kvol, false, 2);
+    const size_t lds = tc_lds_bytes(CIN, COUT, 32, kvol, bf16, 2, planes);
     int per_cu = (int)((size_t)160 * 1024 / lds);
     if (24 / nw < per_cu) per_cu = 24 / nw;
     return (long long)per_cu * 256 >= (rows + tr - 1) / tr;
@@ -1119,6 +1147,97 @@ extern "C" int lcf_indice_conv_fwd_bf16(const float *feat, const void *wimg_bf16
     CV_BF16_CASE(64, 32) CV_BF16_CASE(64, 64) CV_BF16_CASE(64, 128)
     CV_BF16_CASE(128, 32) CV_BF16_CASE(128, 64) CV_BF16_CASE(128, 128)
 #undef CV_BF16_CASE
+    return LCF_ERR_UNSUPPORTED;
+}
+
+// -------------------------------------------------------------------------- bf16x3 entry points
+__global__ void __launch_bounds__(256)
+cv_weight_image_bf16x3_kernel(const float *__restrict__ w, int kvol, int cin, int cout, int CIN,
+                              int COUT, int transpose, __bf16 *__restrict__ img)
+{
+    // two planes of the bf16 image (cv_weight_image_bf16_kernel): hi = bf16(w), lo = bf16(w - hi)
+    const int KS = CIN / 32;
+    long long total = (long long)kvol * CIN * COUT;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+         e += (long long)gridDim.x * blockDim.x) {
+        int o = (int)(e / (CIN * COUT));
+        int r = (int)(e - (long long)o * CIN * COUT);
+        int j = r & 7, r16 = (r >> 3) & 15, q = (r >> 7) & 3;
+        int ks = (r >> 9) % KS, tg = (r >> 9) / KS;
+        int k = 32 * ks + 8 * q + j, c = 16 * tg + r16;
+        float v = 0.f;
+        if (!transpose) {
+            if (k < cin && c < cout) v = w[((size_t)o * cin + k) * cout + c];
+        } else {
+            if (k < cout && c < cin) v = w[((size_t)o * cin + c) * cout + k];
+        }
+        const __bf16 h = (__bf16)v;
+        img[e] = h;
+        img[total + e] = (__bf16)(v - (float)h);
+    }
+}
+
+extern "C" int lcf_weight_image_bf16x3(const float *w, int kvol, int cin, int cout, int transpose,
+                                       void *img, void *stream)
+{
+    if (!w || !img || kvol <= 0 || cin <= 0 || cout <= 0) return LCF_ERR_ARG;
+    if (!cv_bf16_ok(cin) || !cv_bf16_ok(cout)) return LCF_ERR_UNSUPPORTED;
+    int CIN = transpose ? cout : cin, COUT = transpose ? cin : cout;
+    long long total = (long long)kvol * CIN * COUT;
+    int nb = (int)((total + 255) / 256);
+    if (nb > 2048) nb = 2048;
+    cv_weight_image_bf16x3_kernel<<<nb, 256, 0, (hipStream_t)stream>>>(
+        w, kvol, cin, cout, CIN, COUT, transpose, (__bf16 *)img);
+    LCF_CHECK_LAUNCH();
+    return LCF_OK;
+}
+
+// same launch-time choices as the fp32 form (cv_launch_tc): balanced tile height, second wave set
+template <int CIN, int COUT>
+static int cv_launch_tc_bf16x3(const float *feat, const float *wimg, const int *nbr, int k_cap,
+                               const int *k_dev, int kvol, int cin, int cout, const float *scale,
+                               const float *shift, int relu, float *out, hipStream_t st,
+                               TcDense dn)
+{
+    const int rows = g_rows_hint > 0 && g_rows_hint < k_cap ? g_rows_hint : k_cap;
+    const int tr = tc_tile_rows(rows);
+    const bool two = g_tc_sets == 2 ||
+                     (g_tc_sets == 0 && tc_two_sets_fit(CIN, COUT, kvol, rows, tr, true, 2));
+    if (two && tc_lds_bytes(CIN, COUT, 32, kvol, true, 2, 2) <= 160 * 1024)
+        return cv_launch_tc_n<CIN, COUT, 32, true, 2, 2>(feat, wimg, nbr, k_cap, k_dev, kvol, cin,
+                                                         cout, scale, shift, relu, out, st, tr, dn);
+    return cv_launch_tc_n<CIN, COUT, 32, true, 1, 2>(feat, wimg, nbr, k_cap, k_dev, kvol, cin,
+                                                     cout, scale, shift, relu, out, st, tr, dn);
+}
+
+extern "C" int lcf_indice_conv_fwd_bf16x3(const float *feat, const void *wimg_bf16x3,
+                                          const int *nbr, int k_out, const int *k_out_dev,
+                                          int kvol, int cin, int cout, const float *scale,
+                                          const float *shift, int relu, float *out,
+                                          const int *dense_coors, int batch, const int shape[3],
+                                          void *stream)
+{
+    if (k_out < 0 || kvol <= 0 || !wimg_bf16x3 || (k_out > 0 && (!feat || !out)) ||
+        (!nbr && kvol != 1) || (dense_coors && (!shape || batch <= 0)))
+        return LCF_ERR_ARG;
+    if (kvol > LCF_MAX_KVOL || !cv_bf16_ok(cin) || !cv_bf16_ok(cout)) return LCF_ERR_UNSUPPORTED;
+    if (((uintptr_t)feat & 15) || ((uintptr_t)wimg_bf16x3 & 15) || ((uintptr_t)out & 15) ||
+        ((uintptr_t)scale & 15) || ((uintptr_t)shift & 15) || ((uintptr_t)dense_coors & 15))
+        return LCF_ERR_ARG;
+    if (k_out >= (1 << 25)) return LCF_ERR_RANGE;
+    if (k_out == 0) return LCF_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const float *wi = (const float *)wimg_bf16x3;
+    TcDense dn{nullptr, 0, 0, 0, 0};
+    if (dense_coors) dn = TcDense{dense_coors, batch, shape[0], shape[1], shape[2]};
+#define CV_X3_CASE(A, B)                                                                      \
+    if (cin == A && cout == B)                                                                \
+        return cv_launch_tc_bf16x3<A, B>(feat, wi, nbr, k_out, k_out_dev, kvol, cin, cout,    \
+                                         scale, shift, relu, out, st, dn);
+    CV_X3_CASE(32, 32) CV_X3_CASE(32, 64) CV_X3_CASE(32, 128)
+    CV_X3_CASE(64, 32) CV_X3_CASE(64, 64) CV_X3_CASE(64, 128)
+    CV_X3_CASE(128, 32) CV_X3_CASE(128, 64) CV_X3_CASE(128, 128)
+#undef CV_X3_CASE
     return LCF_ERR_UNSUPPORTED;
 }
 

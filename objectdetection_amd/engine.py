@@ -43,10 +43,16 @@ class _Layer:
 
 class FrameEngine:
     def __init__(self, model, max_points=None, calib=None, margin=1.5, use_graph=True,
-                 two_streams=True):
+                 two_streams=True, conv_math="f32"):
         """model: objectdetection_amd.frontend.SparseFrontEnd in eval mode on a GPU.
         max_points: capacity of the point buffer (default: 2 x the largest calibration cloud).
-        calib: list of [N,F] float32 cuda clouds used to size the strided levels."""
+        calib: list of [N,F] float32 cuda clouds used to size the strided levels.
+        conv_math: "f32" (fp32 MFMA, the default) or "bf16x3" (split operands on the bf16 matrix
+        cores, lcf_indice_conv_fwd_bf16x3: ~1e-5 of the features' max magnitude instead of ~1e-7,
+        inside the 1e-4 feature tolerance; layers with 32/64/128 channels on both sides)."""
+        if conv_math not in ("f32", "bf16x3"):
+            raise ValueError("conv_math must be 'f32' or 'bf16x3'")
+        self.conv_math = conv_math
         p = next(model.parameters(), None)
         self.dev = p.device if p is not None else torch.device("cuda", torch.cuda.current_device())
         if self.dev.type != "cuda":
@@ -141,7 +147,8 @@ class FrameEngine:
         """Weight images and folded BatchNorm (eval) of every layer; VFE linear images."""
         with torch.no_grad():
             for l in self.layers:
-                l.wimg = ops.weight_image(l.conv.weight)
+                l.x3 = self.conv_math == "bf16x3" and ops.bf16_supported(l.cin, l.cout)
+                l.wimg = (ops.weight_image_bf16x3 if l.x3 else ops.weight_image)(l.conv.weight)
                 scale = shift = None
                 if l.bn is not None:
                     scale, shift = _bn_affine(l.bn)
@@ -371,20 +378,25 @@ class FrameEngine:
             L.lcf_set_option(_lib.OPT_CONV_ROWS_HINT, int(need[lvl]) if need else 0)
             if not l.subm:
                 coors, kd = l.out_coors, l.k_out
-            if l is self.layers[-1] and self.fuse_dense and l.cout in (16, 32, 64, 128):
-                # dense() in the epilogue of the last conv: its rows go straight to [1,C,D,H,W]
-                if self.two_streams:
-                    main.wait_event(e_dense)
+            # dense() in the epilogue of the last conv: its rows go straight to [1,C,D,H,W]
+            to_dense = l is self.layers[-1] and self.fuse_dense and l.cout in (16, 32, 64, 128)
+            if to_dense and self.two_streams:
+                main.wait_event(e_dense)
+            if l.x3:
+                check(L.lcf_indice_conv_fwd_bf16x3(
+                    P(feat), P(l.wimg), P(o.nbr), k_out_cap, P(k_out_dev), l.kvol, l.cin, l.cout,
+                    P(l.scale), P(l.shift), int(l.relu), P(self.dense if to_dense else l.out),
+                    P(coors) if to_dense else None, 1, i3(self.out_shape), st))
+            elif to_dense:
                 check(L.lcf_indice_conv_fwd_dense(
                     P(feat), P(l.wimg), P(o.nbr), k_out_cap, P(k_out_dev), l.kvol, l.cin, l.cout,
                     P(l.scale), P(l.shift), int(l.relu), P(coors), 1, i3(self.out_shape),
                     P(self.dense), st))
-                feat = None
-                break
-            check(L.lcf_indice_conv_fwd(P(feat), P(l.wimg), P(o.nbr), k_out_cap, P(k_out_dev),
-                                        l.kvol, l.cin, l.cout, P(l.scale), P(l.shift),
-                                        int(l.relu), P(l.out), st))
-            feat = l.out
+            else:
+                check(L.lcf_indice_conv_fwd(P(feat), P(l.wimg), P(o.nbr), k_out_cap,
+                                            P(k_out_dev), l.kvol, l.cin, l.cout, P(l.scale),
+                                            P(l.shift), int(l.relu), P(l.out), st))
+            feat = None if to_dense else l.out
         L.lcf_set_option(_lib.OPT_CONV_ROWS_HINT, 0)
         if feat is not None:
             if self.two_streams:

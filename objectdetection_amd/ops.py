@@ -280,6 +280,42 @@ def conv_forward_bf16(features, wimg, nbr, n_rows, kvol, cin, cout, scale=None, 
     return out
 
 
+def weight_image_bf16x3(weight, transpose=False):
+    """weight [...,Cin,Cout] -> two-plane (hi, lo) bf16 image for lcf_indice_conv_fwd_bf16x3."""
+    _need_cuda(weight)
+    w = weight.detach().float().contiguous()
+    cin, cout = int(w.shape[-2]), int(w.shape[-1])
+    kvol = w.numel() // (cin * cout)
+    img = torch.empty((2 * kvol * cin * cout,), dtype=torch.int16, device=w.device)
+    check(_lib.lib().lcf_weight_image_bf16x3(_ptr(w), kvol, cin, cout, int(transpose), _ptr(img),
+                                             _stream()))
+    return img
+
+
+def conv_forward_bf16x3(features, wimg, nbr, n_rows, kvol, cin, cout, scale=None, shift=None,
+                        relu=False, n_rows_dev=None, out=None, dense_coors=None, batch_size=1,
+                        shape=None):
+    """conv_forward at fp32 tolerance on the bf16 matrix cores: operands split into hi + lo bf16
+    planes, three products per term, fp32 accumulation (include/lcf.h).  With ``dense_coors`` the
+    rows land in the dense [batch, cout, D, H, W] tensor (``out`` must then be cleared)."""
+    _need_cuda(features, wimg, nbr)
+    x = features.contiguous()
+    if dense_coors is not None:
+        if out is None:
+            out = torch.zeros((int(batch_size), cout, *shape), dtype=torch.float32,
+                              device=x.device)
+        dc, sh = dense_coors.contiguous(), i3(shape)
+    else:
+        if out is None:
+            out = torch.empty((n_rows, cout), dtype=torch.float32, device=x.device)
+        dc, sh = None, None
+    check(_lib.lib().lcf_indice_conv_fwd_bf16x3(
+        _ptr(x), _ptr(wimg), _ptr(nbr), int(n_rows), _ptr(n_rows_dev), int(kvol), int(cin),
+        int(cout), _ptr(scale), _ptr(shift), int(bool(relu)), _ptr(out), _ptr(dc),
+        int(batch_size), sh, _stream()))
+    return out
+
+
 def conv_forward(features, wimg, nbr, n_rows, kvol, cin, cout, scale=None, shift=None,
                  relu=False, n_rows_dev=None, out=None):
     """out[n_rows,cout] = act((sum_o features[nbr[n][o]] @ W[o]) * scale + shift).

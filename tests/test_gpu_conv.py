@@ -229,6 +229,79 @@ def test_conv_with_dense_epilogue_equals_conv_then_dense(oracle, cuda, cin, cout
         L.lcf_set_option(_lib.OPT_CONV_SETS, 0)
 
 
+X3_RTOL = 1e-4  # the north-star fp32 feature tolerance; measured: <= 1e-5
+
+
+@pytest.mark.parametrize("cin,cout,subm,sets", [(32, 32, True, 1), (64, 64, True, 2),
+                                                (32, 64, False, 1), (64, 128, True, 1),
+                                                (128, 64, False, 2), (128, 128, True, 1)])
+def test_bf16x3_forward_matches_oracle_at_fp32_tolerance(oracle, cuda, cin, cout, subm, sets):
+    """Split-operand form (x = hi + lo in bf16, three matrix-core products, fp32 accumulation)
+    against the oracle inside the fp32 tolerance, an order of magnitude tighter in practice; exact
+    where hi + lo represents the operands exactly; the dense-target epilogue; determinism."""
+    from objectdetection_amd import _lib
+    rng = np.random.default_rng(cin * 5 + cout + sets)
+    coors = _frame_coors(oracle, 4, 6000)
+    extra = coors.copy()
+    extra[:, 3] = np.minimum(extra[:, 3] + 1, 1407)
+    coors = np.ascontiguousarray(np.unique(np.concatenate([coors, extra], 0), axis=0))
+    shape = [41, 1600, 1408]
+    k = coors.shape[0]
+    # magnitudes over several octaves: the split must hold per element, not per tensor
+    x = (rng.standard_normal((k, cin)) * np.exp2(rng.integers(-6, 7, (k, 1)))).astype(np.float32)
+    w = (rng.standard_normal((3, 3, 3, cin, cout)) / np.sqrt(27 * cin)).astype(np.float32)
+    sc = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+    sh = rng.standard_normal(cout).astype(np.float32)
+    if subm:
+        pairs, pn = oracle.rulebook_subm(coors, 1, shape, 3)
+        k_out = k
+    else:
+        oc, pairs, pn, _ = oracle.rulebook_conv(coors, 1, shape, 3, 2, 1)
+        k_out = oc.shape[0]
+    ref = np.maximum(oracle.indice_conv_fwd(x, w, pairs, pn, k_out) * sc[None] + sh[None], 0)
+    rb = ops.build_rulebook(torch.from_numpy(coors).to(cuda), 1, shape, 3, 2, 1, 1, subm)
+    xt, wt = torch.from_numpy(x).to(cuda), torch.from_numpy(w).to(cuda)
+    sct, sht = torch.from_numpy(sc).to(cuda), torch.from_numpy(sh).to(cuda)
+    img = ops.weight_image_bf16x3(wt)
+    L = _lib.lib()
+    try:
+        assert L.lcf_set_option(_lib.OPT_CONV_SETS, sets) == 0
+        out = ops.conv_forward_bf16x3(xt, img, rb.out_nbr, rb.k_out, 27, cin, cout, sct, sht, True)
+        again = ops.conv_forward_bf16x3(xt, img, rb.out_nbr, rb.k_out, 27, cin, cout, sct, sht,
+                                        True)
+        err = rel_err(out.cpu().numpy(), ref)
+        assert err < X3_RTOL
+        assert err < 2e-5  # what the construction gives (3 * 2^-18 per product, random signs)
+        assert torch.equal(out, again)
+        # operands with <= 16 significant bits are hi + lo exactly: what remains is the dropped
+        # lo*lo term (<= 2^-18 per product) and the fp32 summation order
+        def q16(a):
+            return (a.view(np.uint32) & np.uint32(0xFFFFFF00)).view(np.float32)
+        xq, wq = q16(x.copy()), q16(w.copy())
+        xqt, wqt = torch.from_numpy(xq).to(cuda), torch.from_numpy(wq).to(cuda)
+        a = ops.conv_forward_bf16x3(xqt, ops.weight_image_bf16x3(wqt), rb.out_nbr, rb.k_out, 27,
+                                    cin, cout)
+        L.lcf_set_option(_lib.OPT_CONV_IMPL, 2)
+        b = ops.conv_forward(xqt, ops.weight_image(wqt), rb.out_nbr, rb.k_out, 27, cin, cout)
+        assert rel_err(a.cpu().numpy(), b.cpu().numpy()) < 4e-6
+        # dense target
+        if not subm:
+            oshape = rb.out_shape
+            sub = [int(v) for v in (oshape[0], 64, 64)]
+            d = ops.conv_forward_bf16x3(xt, img, rb.out_nbr, rb.k_out, 27, cin, cout, sct, sht,
+                                        True, dense_coors=rb.out_indices, batch_size=1, shape=sub)
+            assert torch.equal(d, ops.dense(out, rb.out_indices, 1, sub))
+    finally:
+        L.lcf_set_option(_lib.OPT_CONV_SETS, 0)
+        L.lcf_set_option(_lib.OPT_CONV_IMPL, 0)
+
+
+def test_bf16x3_rejects_unsupported_widths(cuda):
+    w = torch.zeros((27, 16, 32), device=cuda)
+    with pytest.raises(RuntimeError):
+        ops.weight_image_bf16x3(w)
+
+
 def test_conv_with_dense_epilogue_rejects_what_it_cannot_do(cuda):
     from objectdetection_amd import _lib
     L = _lib.lib()

@@ -132,3 +132,25 @@ def test_engine_append_keeps_the_cloud_on_the_device(cuda):
             assert torch.equal(out, model([cloud]))
         with pytest.raises(RuntimeError):
             eng.forward_append(torch.zeros((40000, 4), device=cuda))
+
+
+@pytest.mark.parametrize("name", ["M1", "M2"])
+def test_engine_bf16x3_stays_inside_the_fp32_feature_tolerance(cuda, name):
+    """conv_math="bf16x3": the 32/64/128-channel layers of the whole stack on split bf16 operands;
+    the network's output against the fp32 module path, relative to its max magnitude, stays
+    inside the north-star 1e-4 (measured ~1e-5), same active cells, deterministic replays."""
+    model = randomize_(SparseFrontEnd(name).eval(), 0).to(cuda)
+    with torch.no_grad():
+        eng = model.engine(calib=_clouds(cuda, [0, 1], 20000), conv_math="bf16x3")
+        assert any(l.x3 for l in eng.layers) and not all(l.x3 for l in eng.layers)
+        for seed, n in [(0, 20000), (7, 3000), (2, 20000)]:
+            c = torch.from_numpy(synth.vkitti_frame(seed, n)).to(cuda)
+            out = eng.forward(c).clone()
+            eng.check()
+            ref = model([c])
+            err = ((out - ref).abs().max() / ref.abs().max()).item()
+            assert err < 1e-4
+            assert err < 3e-5
+            assert torch.equal(eng.forward(c), out)
+    with pytest.raises(ValueError):
+        model.engine(calib=_clouds(cuda, [0], 3000), conv_math="bf16")

@@ -39,15 +39,17 @@ def main():
             layers.append((f"{'subm' if conv.subm else 'conv'} {conv.in_channels}->"
                            f"{conv.out_channels} K={rb.k_out}", args, pairs))
             x = conv(x, _scale=scale, _shift=shift, _relu=True)
-    bf16_imgs = {}
+    bf16_imgs, x3_imgs = {}, {}
     mods_c = [m for m in mid.middle_conv if hasattr(m, "subm")]
     for li, conv in enumerate(mods_c):
         if ops.bf16_supported(conv.in_channels, conv.out_channels):
             bf16_imgs[li] = ops.weight_image_bf16(conv.weight)
+            x3_imgs[li] = ops.weight_image_bf16x3(conv.weight)
     torch.cuda.synchronize()
     reps, rounds = 10, 5
     # slab; split-slab; tile-compacted: 1 set fixed 32-row tiles, 1 set, 2 sets (balanced tiles); bf16
-    splits = [1, "ss", "tc1_32", "tc1", "tc2", "bf16"]
+    # x3_1 / x3_2: split-operand (bf16x3) form with one / two wave sets
+    splits = [1, "ss", "tc1_32", "tc1", "tc2", "bf16", "x3_1", "x3_2"]
     res = {}
     for r in range(rounds):
         for sp in splits:
@@ -55,6 +57,8 @@ def main():
             L.lcf_set_option(2, 32 if sp == "tc1_32" else 0)
             if sp == "bf16":
                 L.lcf_set_option(1, 0)
+            elif sp in ("x3_1", "x3_2"):
+                L.lcf_set_option(3, 1 if sp == "x3_1" else 2)
             elif sp == "ss":
                 L.lcf_set_option(1, 3)
             elif sp == 1:
@@ -70,6 +74,12 @@ def main():
                         continue
                     fwd = ops.conv_forward_bf16
                     args = (args[0], bf16_imgs[li]) + args[2:]
+                if sp in ("x3_1", "x3_2"):
+                    if not ops.bf16_supported(args[5], args[6]):
+                        res.setdefault((li, sp), []).append(float("nan"))
+                        continue
+                    fwd = ops.conv_forward_bf16x3
+                    args = (args[0], x3_imgs[li]) + args[2:]
                 fwd(*args)
                 e0 = torch.cuda.Event(enable_timing=True)
                 e1 = torch.cuda.Event(enable_timing=True)
@@ -94,6 +104,12 @@ def main():
             row += f"{us:9.1f}/{2.0 * pairs * cin * cout / us / 1e6:5.1f} "
         print(row)
     print("total us:", {sp: round(v, 1) for sp, v in tot.items()})
+    # error of the split-operand form against the fp32 kernel, relative to the max magnitude
+    for li, (name, args, pairs) in enumerate(layers):
+        if li in x3_imgs:
+            a = ops.conv_forward(*args)
+            b = ops.conv_forward_bf16x3(args[0], x3_imgs[li], *args[2:])
+            print(f"x3 vs fp32 {name:30s} {float((a - b).abs().max() / a.abs().max()):.2e}")
 
 
 if __name__ == "__main__":
