@@ -215,6 +215,16 @@ int lcf_indice_conv_fwd_dense(const float *feat, const float *wimg, const int *n
 int lcf_indice_conv_wgrad(const float *feat, const float *dout, const int *in_nbr, int k_in,
                           int kvol, int cin, int cout, float *dw, void *stream);
 
+/* wgrad on the bf16 matrix cores (K dimension of one MFMA = 32 pairs).  planes = 1: operands
+ * rounded to bf16, fp32 accumulation (BASELINE.json configs[2], tolerance 2e-2 of max |dw|);
+ * planes = 2: operands split hi + lo as in lcf_indice_conv_fwd_bf16x3, three products per term
+ * (fp32 tolerance 1e-4; measured ~1e-5).  feat / dout row-major f32 with exactly cin / cout
+ * columns, cin, cout in {32, 64, 128} and cin * cout <= 4096 (LCF_ERR_UNSUPPORTED otherwise: the
+ * caller keeps lcf_indice_conv_wgrad).  dw [kvol,cin,cout] f32 is zeroed inside. */
+int lcf_indice_conv_wgrad_bf16(const float *feat, const float *dout, const int *in_nbr, int k_in,
+                               int kvol, int cin, int cout, int planes, float *dw,
+                               void *stream);
+
 /* Fill `bytes` (multiple of 4, 4-byte aligned) with a 32-bit pattern: a plain kernel, usable
  * where hipMemsetAsync is not wanted (graph capture; no counterpart in the reference). */
 int lcf_fill_u32(void *p, uint32_t value, size_t bytes, void *stream);

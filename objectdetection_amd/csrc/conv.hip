@@ -14,6 +14,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include <type_traits>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -609,6 +610,10 @@ cv_tc_kernel(const float *__restrict__ feat, const float *__restrict__ wimg,
     const int k_out = lcf_count(k_cap, k_dev);
     // tr <= TR rows per tile (host: chosen so that the tiles divide evenly over the CUs); every
     // buffer is laid out for TR rows
+    // (tile = blockIdx.x: workgroups go round-robin to the 8 XCDs.  Giving XCD x the x-th
+    // contiguous eighth of the tiles instead, so that one L2 holds a neighbourhood's rows, was
+    // measured: 7 % slower -- the feature matrix fits the L2s either way and round-robin
+    // balances the per-tile work across XCDs.)
     const int row0 = blockIdx.x * tr;
     if (row0 >= k_out) return;
 
@@ -1251,6 +1256,21 @@ extern "C" int lcf_indice_conv_fwd_bf16x3(const float *feat, const void *wimg_bf
 // current 4.  The four partial dW[o] are summed in LDS and added to HBM once per workgroup
 // (fp32 atomics: the sum order across workgroups is not reproducible in the last bits).
 
+// Workgroup -> (row chunk, offset).  Workgroups go round-robin to the 8 XCDs (id % 8), each with
+// its own 4 MB L2; the 27 offsets of one chunk read the same feat rows and neighbouring dout
+// rows, so they are given consecutive slots on ONE XCD: id = 8 * (group * kvol + o) + xcd,
+// chunk = 8 * group + xcd.  Against a (chunk, offset) grid in launch order, batch 8 (294k rows,
+// 150 MB of operands, far beyond the L2s): 32->32 256 -> 168 us, strided 32->64 210 -> 100 us,
+// the split-operand 64->64 392 -> 300 us.  Grid: 8 * ceil(nchunk / 8) * kvol workgroups.
+__device__ __forceinline__ bool wg_chunk_offset(int nchunk, int kvol, int &chunk, int &o)
+{
+    const int id = blockIdx.x, t = id >> 3;
+    const int g = t / kvol;
+    o = t - g * kvol;
+    chunk = g * 8 + (id & 7);
+    return chunk < nchunk;
+}
+
 template <int CIN, int COUT>
 __global__ void __launch_bounds__(256)
 cv_wgrad_kernel(const float *__restrict__ feat, const float *__restrict__ dout,
@@ -1261,13 +1281,14 @@ cv_wgrad_kernel(const float *__restrict__ feat, const float *__restrict__ dout,
     constexpr int NT = COUT / 16; // col tiles of dW (co)
     __shared__ float red[CIN * COUT];
     __shared__ int any_s;
-    const int o = blockIdx.y;
+    int chunk, o;
+    if (!wg_chunk_offset((k_in + wg_rows - 1) / wg_rows, kvol, chunk, o)) return;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int r16 = lane & 15;
     const int q = lane >> 4;
-    const int wbeg = blockIdx.x * wg_rows + wave * (wg_rows / 4);
+    const int wbeg = chunk * wg_rows + wave * (wg_rows / 4);
 
     for (int e = tid; e < CIN * COUT; e += 256) red[e] = 0.f;
     if (tid == 0) any_s = 0;
@@ -1386,6 +1407,140 @@ cv_wgrad_kernel(const float *__restrict__ feat, const float *__restrict__ dout,
         const int ci = e / COUT, co = e % COUT;
         if (ci < cin && co < cout) atomicAdd(&dwo[(size_t)ci * cout + co], red[e]);
     }
+}
+
+// wgrad on the bf16 matrix cores.  Same decomposition as cv_wgrad_kernel (workgroup = offset x
+// row chunk, pairs compacted inside the wave), but the K dimension of one
+// v_mfma_f32_16x16x32_bf16 is 32 pairs: lane quarter q takes pairs 8q .. 8q+7 of the step and
+// issues its 16 row loads (8 of feat, 8 of dout, 16 bytes each at 64 channels) at once; component
+// m of the eight loaded vectors is the A fragment of dW tile row m (B alike), so the fragments are
+// built in registers with no LDS transpose.  NP = 1: operands rounded to bf16 (the training
+// variant of BASELINE.json configs[2]).  NP = 2: operands split hi + lo as in the bf16x3 forward,
+// three products per term: fp32-grade gradients (<= 3 * 2^-18 per product) at 3/16 of the fp32
+// MFMA cycles, and on the pipe that overlaps the conversions.
+template <int CIN, int COUT, int NP>
+__global__ void __launch_bounds__(256)
+cv_wgrad_mc_kernel(const float *__restrict__ feat, const float *__restrict__ dout,
+                   const int *__restrict__ in_nbr, int k_in, int kvol, int wg_rows,
+                   float *__restrict__ dw)
+{
+    constexpr int MT = CIN / 16, NT = COUT / 16;
+    static_assert(MT % 2 == 0 && NT % 2 == 0, "32, 64 or 128 channels");
+    __shared__ float red[CIN * COUT];
+    __shared__ int any_s;
+    int chunk, o;
+    if (!wg_chunk_offset((k_in + wg_rows - 1) / wg_rows, kvol, chunk, o)) return;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int r16 = lane & 15;
+    const int q = lane >> 4;
+    const int wbeg = chunk * wg_rows + wave * (wg_rows / 4);
+
+    for (int e = tid; e < CIN * COUT; e += 256) red[e] = 0.f;
+    if (tid == 0) any_s = 0;
+    __syncthreads();
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    bool any_total = false;
+
+    // one row's MT (NT) consecutive channels of this lane
+    auto load_row = [&](const float *p, float *v, auto cnt) {
+        constexpr int N = decltype(cnt)::value;
+        if constexpr (N % 4 == 0) {
+#pragma unroll
+            for (int m = 0; m < N; m += 4) {
+                float4 x = *reinterpret_cast<const float4 *>(p + m);
+                v[m] = x.x; v[m + 1] = x.y; v[m + 2] = x.z; v[m + 3] = x.w;
+            }
+        } else {
+            float2 x = *reinterpret_cast<const float2 *>(p);
+            v[0] = x.x; v[1] = x.y;
+        }
+    };
+
+    for (int blk = 0; blk < wg_rows / 4 / 64; ++blk) {
+        const int row = wbeg + blk * 64 + lane;
+        const int nb = row < k_in ? in_nbr[(size_t)row * kvol + o] : -1;
+        const unsigned long long mk = __ballot(nb >= 0);
+        if (mk == 0ull) continue; // wave-uniform
+        any_total = true;
+        const int c = __popcll(mk);
+        const unsigned long long lt = (1ull << lane) - 1ull;
+        const int slot = nb >= 0 ? __popcll(mk & lt) : c + __popcll(~mk & lt);
+        const int cj = __builtin_amdgcn_ds_permute(slot * 4, row);
+        const int cn = __builtin_amdgcn_ds_permute(slot * 4, nb);
+        for (int s0 = 0; s0 < c; s0 += 32) { // one or two steps of 32 pairs
+            float xa[8][MT], xb[8][NT];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int s = s0 + 8 * q + j;
+                const int rj = __shfl(cj, s & 63, 64);
+                const int rn = __shfl(cn, s & 63, 64);
+                if (s < c) {
+                    load_row(feat + (size_t)rj * CIN + MT * r16, xa[j],
+                             std::integral_constant<int, MT>{});
+                    load_row(dout + (size_t)rn * COUT + NT * r16, xb[j],
+                             std::integral_constant<int, NT>{});
+                } else {
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) xa[j][m] = 0.f;
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) xb[j][n] = 0.f;
+                }
+            }
+            bf16x8 bh[NT], bl[NP == 2 ? NT : 1];
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const __bf16 h = (__bf16)xb[j][n];
+                    bh[n][j] = h;
+                    if constexpr (NP == 2) bl[n][j] = (__bf16)(xb[j][n] - (float)h);
+                }
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                bf16x8 ah, al;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const __bf16 h = (__bf16)xa[j][m];
+                    ah[j] = h;
+                    if constexpr (NP == 2) al[j] = (__bf16)(xa[j][m] - (float)h);
+                }
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    if constexpr (NP == 2) {
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[n], acc[m][n],
+                                                                            0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[n], acc[m][n],
+                                                                            0, 0, 0);
+                    }
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[n], acc[m][n], 0,
+                                                                        0, 0);
+                }
+            }
+        }
+    }
+    if (any_total) any_s = 1;
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w && any_total) {
+#pragma unroll
+            for (int mm = 0; mm < MT; ++mm)
+#pragma unroll
+                for (int nn = 0; nn < NT; ++nn)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        red[(MT * (q * 4 + r) + mm) * COUT + NT * r16 + nn] += acc[mm][nn][r];
+        }
+        __syncthreads();
+    }
+    if (!any_s) return;
+    float *dwo = dw + (size_t)o * CIN * COUT;
+    for (int e = tid; e < CIN * COUT; e += 256) atomicAdd(&dwo[e], red[e]);
 }
 
 // -------------------------------------------------------------------------- host side
@@ -1596,11 +1751,54 @@ static int cv_launch_wgrad(const float *feat, const float *dout, const int *in_n
     int wg_rows = (int)((want + 255) / 256 * 256);
     if (wg_rows < 256) wg_rows = 256;
     if (wg_rows > 16384) wg_rows = 16384;
-    dim3 grid((k_in + wg_rows - 1) / wg_rows, kvol);
+    const int nchunk = (k_in + wg_rows - 1) / wg_rows;
+    const dim3 grid(((nchunk + 7) / 8) * 8 * kvol, 1);
     cv_wgrad_kernel<(CIN < 16 ? 16 : CIN), COUT><<<grid, 256, 0, st>>>(
         feat, dout, in_nbr, k_in, kvol, cin, cout, wg_rows, dw);
     LCF_CHECK_LAUNCH();
     return LCF_OK;
+}
+
+template <int CIN, int COUT>
+static int cv_launch_wgrad_mc(const float *feat, const float *dout, const int *in_nbr, int k_in,
+                              int kvol, int planes, float *dw, hipStream_t st)
+{
+    long long want = ((long long)k_in * kvol + 2999) / 3000;
+    int wg_rows = (int)((want + 255) / 256 * 256);
+    if (wg_rows < 256) wg_rows = 256;
+    if (wg_rows > 16384) wg_rows = 16384;
+    const int nchunk = (k_in + wg_rows - 1) / wg_rows;
+    const dim3 grid(((nchunk + 7) / 8) * 8 * kvol, 1);
+    if (planes == 2)
+        cv_wgrad_mc_kernel<CIN, COUT, 2><<<grid, 256, 0, st>>>(feat, dout, in_nbr, k_in, kvol,
+                                                               wg_rows, dw);
+    else
+        cv_wgrad_mc_kernel<CIN, COUT, 1><<<grid, 256, 0, st>>>(feat, dout, in_nbr, k_in, kvol,
+                                                               wg_rows, dw);
+    LCF_CHECK_LAUNCH();
+    return LCF_OK;
+}
+
+extern "C" int lcf_indice_conv_wgrad_bf16(const float *feat, const float *dout,
+                                          const int *in_nbr, int k_in, int kvol, int cin,
+                                          int cout, int planes, float *dw, void *stream)
+{
+    if (k_in < 0 || kvol <= 0 || cin <= 0 || cout <= 0 || !dw || (planes != 1 && planes != 2) ||
+        (k_in > 0 && (!feat || !dout || !in_nbr)))
+        return LCF_ERR_ARG;
+    if (kvol > LCF_MAX_KVOL || !cv_bf16_ok(cin) || !cv_bf16_ok(cout) || cin * cout > 4096)
+        return LCF_ERR_UNSUPPORTED;
+    if (((uintptr_t)feat & 15) || ((uintptr_t)dout & 15)) return LCF_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (lcf_fill32(dw, 0u, (size_t)kvol * cin * cout * 4, st) != LCF_OK) return LCF_ERR_LAUNCH;
+    if (k_in == 0) return LCF_OK;
+#define CV_WMC_CASE(A, B)                                                                     \
+    if (cin == A && cout == B)                                                                \
+        return cv_launch_wgrad_mc<A, B>(feat, dout, in_nbr, k_in, kvol, planes, dw, st);
+    CV_WMC_CASE(32, 32) CV_WMC_CASE(32, 64) CV_WMC_CASE(64, 32) CV_WMC_CASE(64, 64)
+    CV_WMC_CASE(32, 128) CV_WMC_CASE(128, 32)
+#undef CV_WMC_CASE
+    return LCF_ERR_UNSUPPORTED;
 }
 
 extern "C" int lcf_indice_conv_wgrad(const float *feat, const float *dout, const int *in_nbr,

@@ -350,10 +350,21 @@ def conv_forward_dense(features, wimg, nbr, n_rows, kvol, cin, cout, out_coors, 
     return out
 
 
-def conv_wgrad(features, dout, in_nbr, kvol, cin, cout):
+def wgrad_mc_supported(cin, cout):
+    return bf16_supported(cin, cout) and cin * cout <= 4096
+
+
+def conv_wgrad(features, dout, in_nbr, kvol, cin, cout, planes=0):
+    """dw [kvol,cin,cout].  planes 0: fp32 MFMA; 1: bf16 operands; 2: split hi + lo bf16 operands
+    (fp32-grade) -- 1 and 2 on the bf16 matrix cores (lcf_indice_conv_wgrad_bf16)."""
     x = features.contiguous()
     g = dout.contiguous()
     dw = torch.empty((kvol, cin, cout), dtype=torch.float32, device=x.device)
+    if planes:
+        check(_lib.lib().lcf_indice_conv_wgrad_bf16(_ptr(x), _ptr(g), _ptr(in_nbr), x.shape[0],
+                                                    int(kvol), int(cin), int(cout), int(planes),
+                                                    _ptr(dw), _stream()))
+        return dw
     check(_lib.lib().lcf_indice_conv_wgrad(_ptr(x), _ptr(g), _ptr(in_nbr), x.shape[0],
                                            int(kvol), int(cin), int(cout), _ptr(dw), _stream()))
     return dw
@@ -392,7 +403,13 @@ class IndiceConvFunction(torch.autograd.Function):
             din = conv_forward(g, weight_image(weight, transpose=True), rb.in_nbr, rb.k_in,
                                rb.kvol, cout, cin).to(ctx.in_dtype)
         if ctx.needs_input_grad[1]:
-            dw = conv_wgrad(x, g, rb.in_nbr, rb.kvol, cin, cout).view_as(weight).to(weight.dtype)
+            # "bf16" conv math: the wide submanifold layers (many pairs per 64 rows) take the
+            # matrix-core wgrad with split hi + lo operands -- fp32-grade gradients, 400 -> 300 us
+            # per 64->64 call at batch 8; strided and narrower layers are faster on fp32 MFMAs
+            planes = 2 if (ctx.bf16 and rb.subm and cin * cout >= 4096
+                           and wgrad_mc_supported(cin, cout)) else 0
+            dw = conv_wgrad(x, g, rb.in_nbr, rb.kvol, cin, cout,
+                            planes).view_as(weight).to(weight.dtype)
         return din, dw, None
 
 

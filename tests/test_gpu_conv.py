@@ -10,6 +10,7 @@ from objectdetection_amd import ops, synth
 pytestmark = pytest.mark.gpu
 
 RTOL = 1e-4  # north-star tolerance for fp32 features (relative to the tensor's max magnitude)
+BF16_RTOL = 2e-2  # stated bf16 tolerance (north star): bf16 operands, fp32 accumulation
 
 
 def rel_err(a, b):
@@ -88,6 +89,56 @@ def test_backward_matches_oracle(oracle, cuda, cin, cout, subm):
     out.backward(torch.from_numpy(g).to(cuda))
     assert rel_err(xt.grad.cpu().numpy(), din_ref) < RTOL
     assert rel_err(wt.grad.cpu().numpy(), dw_ref) < RTOL
+
+
+@pytest.mark.parametrize("cin,cout,subm", [(32, 32, True), (64, 64, True), (32, 64, False),
+                                           (64, 32, True), (32, 128, False), (128, 32, True)])
+def test_matrix_core_wgrad_matches_oracle(oracle, cuda, cin, cout, subm):
+    """lcf_indice_conv_wgrad_bf16: split operands (planes = 2) inside the fp32 tolerance, plain
+    bf16 operands (planes = 1) inside the stated bf16 tolerance, both against the oracle; rows
+    with magnitudes over several octaves; blocks with more than 32 pairs per 64 rows (two steps)
+    and with none."""
+    rng = np.random.default_rng(3 * cin + cout)
+    coors = _frame_coors(oracle, 6, 5000)
+    extra = coors.copy()
+    extra[:, 3] = np.minimum(extra[:, 3] + 1, 1407)
+    coors = np.ascontiguousarray(np.unique(np.concatenate([coors, extra], 0), axis=0))
+    shape = [41, 1600, 1408]
+    k = coors.shape[0]
+    x = (rng.standard_normal((k, cin)) * np.exp2(rng.integers(-4, 5, (k, 1)))).astype(np.float32)
+    w = np.zeros((3, 3, 3, cin, cout), np.float32)
+    if subm:
+        pairs, pn = oracle.rulebook_subm(coors, 1, shape, 3)
+        k_out = k
+    else:
+        oc, pairs, pn, _ = oracle.rulebook_conv(coors, 1, shape, 3, 2, 1)
+        k_out = oc.shape[0]
+    g = (rng.standard_normal((k_out, cout)) *
+         np.exp2(rng.integers(-4, 5, (k_out, 1)))).astype(np.float32)
+    _, dw_ref = oracle.indice_conv_bwd(x, w, g, pairs, pn)
+    dw_ref = dw_ref.reshape(27, cin, cout)
+    rb = ops.build_rulebook(torch.from_numpy(coors).to(cuda), 1, shape, 3, 2, 1, 1, subm)
+    xt, gt = torch.from_numpy(x).to(cuda), torch.from_numpy(g).to(cuda)
+    assert ops.wgrad_mc_supported(cin, cout)
+    d2 = ops.conv_wgrad(xt, gt, rb.in_nbr, 27, cin, cout, planes=2).cpu().numpy()
+    d1 = ops.conv_wgrad(xt, gt, rb.in_nbr, 27, cin, cout, planes=1).cpu().numpy()
+    d0 = ops.conv_wgrad(xt, gt, rb.in_nbr, 27, cin, cout).cpu().numpy()
+    assert rel_err(d0, dw_ref) < RTOL
+    assert rel_err(d2, dw_ref) < RTOL
+    assert rel_err(d2, dw_ref) < 2e-5
+    assert rel_err(d1, dw_ref) < BF16_RTOL
+    # per offset too: an offset with few pairs must not hide behind the centre's magnitude
+    for o in range(27):
+        if np.abs(dw_ref[o]).max() > 0:
+            assert rel_err(d2[o], dw_ref[o]) < RTOL
+
+
+def test_matrix_core_wgrad_rejects_unsupported_shapes(cuda):
+    assert not ops.wgrad_mc_supported(16, 32) and not ops.wgrad_mc_supported(128, 64)
+    t = torch.zeros((8, 16), device=cuda)
+    n = torch.full((8, 27), -1, dtype=torch.int32, device=cuda)
+    with pytest.raises(RuntimeError):
+        ops.conv_wgrad(t, torch.zeros((8, 32), device=cuda), n, 27, 16, 32, planes=2)
 
 
 def test_linearity_and_determinism_full_size(oracle, cuda):
@@ -324,9 +375,6 @@ def test_option_values_are_validated(cuda):
     assert L.lcf_set_option(_lib.OPT_CONV_IMPL, 4) != 0
     assert L.lcf_set_option(_lib.OPT_WS_CLEAN, 2) != 0
     assert L.lcf_set_option(99, 0) != 0
-
-
-BF16_RTOL = 2e-2  # stated bf16 tolerance (north star): bf16 operands, fp32 accumulation
 
 
 @pytest.mark.parametrize("cin,cout,subm", [(32, 32, True), (64, 64, True), (32, 64, False),
