@@ -612,8 +612,8 @@ cv_tc_kernel(const float *__restrict__ feat, const float *__restrict__ wimg,
     // buffer is laid out for TR rows
     // (tile = blockIdx.x: workgroups go round-robin to the 8 XCDs.  Giving XCD x the x-th
     // contiguous eighth of the tiles instead, so that one L2 holds a neighbourhood's rows, was
-    // measured: 7 % slower -- the feature matrix fits the L2s either way and round-robin
-    // balances the per-tile work across XCDs.)
+    // measured: 7 % slower on one frame (38k rows: the features fit the L2s either way and
+    // round-robin balances the per-tile work) and no different at batch 8 (294k rows).)
     const int row0 = blockIdx.x * tr;
     if (row0 >= k_out) return;
 

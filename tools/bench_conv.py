@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-layer timing of the indice_conv forward on the real rulebooks of one synthetic frame.
-Interleaved rounds in one process (MI355X guide rule 24).  Usage: python tools/bench_conv.py"""
+Interleaved rounds in one process (MI355X guide rule 24).  Usage: python tools/bench_conv.py [points] [batch]"""
 import os
 import sys
 
@@ -19,15 +19,16 @@ def main():
         _lib.LIB_PATH = os.path.abspath(os.environ["LCF_LIB"])
     dev = torch.device("cuda:0")
     model = randomize_(SparseFrontEnd("M2").eval(), 0).to(dev)
-    cloud = torch.from_numpy(synth.vkitti_frame(0, n) if n <= 40000 else
-                             synth.synthia_frame(0, n)).to(dev)
+    batch = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    clouds = [torch.from_numpy(synth.vkitti_frame(i, n) if n <= 40000 else
+                               synth.synthia_frame(i, n)).to(dev) for i in range(batch)]
     L = _lib.lib()
     layers = []
     with torch.no_grad():
-        voxels, num, coors = model.voxelize([cloud])
+        voxels, num, coors = model.voxelize(clouds)
         feats = model.voxel_feature_extractor(voxels, num, coors)
         mid = model.middle_feature_extractor
-        x = SparseConvTensor(feats, coors, mid.sparse_shape, 1)
+        x = SparseConvTensor(feats, coors, mid.sparse_shape, batch)
         mods = list(mid.middle_conv)
         for i in range(0, len(mods), 3):
             conv, bn = mods[i], mods[i + 1]
