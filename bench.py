@@ -124,7 +124,8 @@ def train_measurement(args, dev, rank, world, dist, barrier):
             "value": round(world * b * args.train_steps / el, 2), "unit": "frames/s",
             "ms_per_step": round(el / args.train_steps * 1e3, 2), "steps": args.train_steps,
             "global_batch": world * b, "scaling": "weak",
-            "dtype": "bf16 MFMA indice_conv fwd/dgrad (fp32 accumulate, fp32 wgrad and master "
+            "dtype": "bf16 MFMA indice_conv fwd/dgrad (fp32 accumulate; wgrad at fp32 tolerance: "
+                     "fp32 MFMA, split hi+lo bf16 operands on the wide layers; fp32 master "
                      "weights), bf16 autocast RPN",
             "allreduce_bytes": 4 * nparams if world > 1 else 0,
             "loss": round(float(loss), 4)}
