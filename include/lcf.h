@@ -239,6 +239,17 @@ int lcf_dense(const float *feat, const int *coors, int k, const int *k_dev, int 
 int lcf_dense_bwd(const float *dout, const int *coors, int k, int c, int batch,
                   const int shape[3], float *dfeat, void *stream);
 
+/* dense() handed to the RPN's first convolution without a layout or dtype pass (SURVEY.md
+ * section 8f-1; middle.py:206-209 + rpn.py:486-495 under bf16 autocast): the [B, C*D, H, W] view
+ * as channels_last bf16, memory [B, H, W, C*D], element (b, c, z, y, x) at
+ * ((b*H + y)*W + x)*(C*D) + c*D + z, rounded to nearest even.  _bwd gathers the gradient of that
+ * tensor (same layout, bf16) back into dfeat [k, c] f32.  B*C*D*H*W must be even. */
+int lcf_dense_nhwc_bf16(const float *feat, const int *coors, int k, const int *k_dev, int c,
+                        int batch, const int shape[3], int zero_fill, void *out_bf16,
+                        void *stream);
+int lcf_dense_nhwc_bf16_bwd(const void *dout_bf16, const int *coors, int k, int c, int batch,
+                            const int shape[3], float *dfeat, void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * VFE streaming kernels (second/pytorch/models/voxel_encoder.py).
  * vfe_mean : SimpleVoxel.forward (:220-225): out[k,:c] = sum_t voxels[k,t,:c] / num[k].

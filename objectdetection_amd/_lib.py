@@ -69,6 +69,10 @@ SYMBOLS = {
                           c_void_p, c_void_p]),
     "lcf_dense_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, _PI3, c_void_p,
                               c_void_p]),
+    "lcf_dense_nhwc_bf16": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, _PI3,
+                                    c_int, c_void_p, c_void_p]),
+    "lcf_dense_nhwc_bf16_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, _PI3, c_void_p,
+                                        c_void_p]),
     "lcf_vfe_mean": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p,
                              c_void_p]),
     "lcf_vfe_augment": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p,

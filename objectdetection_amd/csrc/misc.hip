@@ -122,6 +122,78 @@ extern "C" int lcf_dense_bwd(const float *dout, const int *coors, int k, int c, 
     return LCF_OK;
 }
 
+// dense() in the layout the RPN's first convolution reads under bf16 autocast: the
+// [B, C*D, H, W] view of middle.py:207-209 as channels_last bf16, i.e. memory [B, H, W, C*D] with
+// element (b, c, z, y, x) at ((b*H + y)*W + x)*(C*D) + c*D + z.  One pass instead of fp32 NCDHW
+// scatter + layout copy + dtype copy (and half the zero fill); the two z-rows of a pillar fill
+// one 2*C*D-byte run.  Rounding: round-to-nearest-even, as torch's float -> bfloat16 copy.
+__global__ void __launch_bounds__(256)
+dense_nhwc_bf16_kernel(const float *__restrict__ feat, const int *__restrict__ coors, int k_cap,
+                       const int *__restrict__ k_dev, int c, int batch, int D, int H, int W,
+                       __bf16 *__restrict__ out)
+{
+    const int k = lcf_count(k_cap, k_dev);
+    long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (long long)k * c) return;
+    int row = (int)(t / c), ch = (int)(t - (long long)row * c);
+    int4 q = reinterpret_cast<const int4 *>(coors)[row];
+    if (q.x < 0 || q.x >= batch || q.y < 0 || q.y >= D || q.z < 0 || q.z >= H || q.w < 0 ||
+        q.w >= W)
+        return;
+    size_t pix = ((size_t)q.x * H + q.z) * W + q.w;
+    out[pix * ((size_t)c * D) + (size_t)ch * D + q.y] = (__bf16)feat[t];
+}
+
+__global__ void __launch_bounds__(256)
+dense_nhwc_bf16_gather_kernel(const __bf16 *__restrict__ dout, const int *__restrict__ coors,
+                              int k, int c, int batch, int D, int H, int W,
+                              float *__restrict__ dfeat)
+{
+    long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (long long)k * c) return;
+    int row = (int)(t / c), ch = (int)(t - (long long)row * c);
+    int4 q = reinterpret_cast<const int4 *>(coors)[row];
+    float v = 0.f;
+    if (q.x >= 0 && q.x < batch && q.y >= 0 && q.y < D && q.z >= 0 && q.z < H && q.w >= 0 &&
+        q.w < W) {
+        size_t pix = ((size_t)q.x * H + q.z) * W + q.w;
+        v = (float)dout[pix * ((size_t)c * D) + (size_t)ch * D + q.y];
+    }
+    dfeat[t] = v;
+}
+
+extern "C" int lcf_dense_nhwc_bf16(const float *feat, const int *coors, int k, const int *k_dev,
+                                   int c, int batch, const int shape[3], int zero_fill,
+                                   void *out_bf16, void *stream)
+{
+    if (k < 0 || c <= 0 || batch <= 0 || !shape || !out_bf16 || (k > 0 && (!feat || !coors)))
+        return LCF_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    size_t bytes = (size_t)batch * c * shape[0] * shape[1] * shape[2] * 2;
+    if (bytes & 3) return LCF_ERR_UNSUPPORTED; // the fill works on 32-bit words
+    if (zero_fill && lcf_fill32(out_bf16, 0u, bytes, st) != LCF_OK) return LCF_ERR_LAUNCH;
+    if (k == 0) return LCF_OK;
+    long long total = (long long)k * c;
+    dense_nhwc_bf16_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(
+        feat, coors, k, k_dev, c, batch, shape[0], shape[1], shape[2], (__bf16 *)out_bf16);
+    LCF_CHECK_LAUNCH();
+    return LCF_OK;
+}
+
+extern "C" int lcf_dense_nhwc_bf16_bwd(const void *dout_bf16, const int *coors, int k, int c,
+                                       int batch, const int shape[3], float *dfeat, void *stream)
+{
+    if (k < 0 || c <= 0 || batch <= 0 || !shape || !dout_bf16 || (k > 0 && (!dfeat || !coors)))
+        return LCF_ERR_ARG;
+    if (k == 0) return LCF_OK;
+    long long total = (long long)k * c;
+    dense_nhwc_bf16_gather_kernel<<<(unsigned)((total + 255) / 256), 256, 0,
+                                    (hipStream_t)stream>>>(
+        (const __bf16 *)dout_bf16, coors, k, c, batch, shape[0], shape[1], shape[2], dfeat);
+    LCF_CHECK_LAUNCH();
+    return LCF_OK;
+}
+
 // ---------------------------------------------------------------- VFE
 // SimpleVoxel.forward (voxel_encoder.py:220-225): sum over T (padding rows are zero) / num.
 // The sum runs t = 0..T-1 in order, as torch's reduction over a 5-long dim does.

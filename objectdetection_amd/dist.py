@@ -40,7 +40,17 @@ class FlatGradAllReduce:
         self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
         off = 0
         for p in self.params:
-            p.grad = self.flat[off:off + p.numel()].view_as(p)
+            seg = self.flat[off:off + p.numel()]
+            if p.is_contiguous():
+                p.grad = seg.view_as(p)
+            elif p.dim() == 4 and p.is_contiguous(memory_format=torch.channels_last):
+                # same physical order as the parameter (autograd's gradient layout contract):
+                # elementwise optimizer kernels then run on matching strides, and the fused
+                # multi-tensor AdamW accepts the pair
+                p.grad = seg.as_strided(p.size(), p.stride())
+            else:
+                raise ValueError("FlatGradAllReduce: parameters must be dense (contiguous or "
+                                 "channels_last)")
             off += p.numel()
 
     def zero(self):

@@ -15,7 +15,7 @@ import numpy as np
 import torch
 from torch import nn
 
-from . import spconv
+from . import ops, spconv
 
 REGISTERED_MIDDLE_CLASSES = {}
 
@@ -97,6 +97,9 @@ def build_middle_conv(layers, num_input_features, use_norm=True):
 
 class _MiddleBase(nn.Module):
     layers_name = None
+    # None: dense() + view as in the reference (fp32 [N, C*D, H, W]).  "rpn_bf16": the same tensor
+    # as channels_last bf16, written in one pass (ops.dense_nhwc_bf16) for an RPN under autocast.
+    dense_to = None
 
     def __init__(self, output_shape, use_norm=True, num_input_features=128,
                  num_filters_down1=[64], num_filters_down2=[64, 64], name=None):
@@ -115,6 +118,9 @@ class _MiddleBase(nn.Module):
         coors = coors.int()
         ret = spconv.SparseConvTensor(voxel_features, coors, self.sparse_shape, batch_size)
         ret = self.middle_conv(ret)
+        if self.dense_to == "rpn_bf16" and ret.features.is_cuda:
+            # straight into the RPN's channels_last bf16 input (no fp32 NCDHW tensor in between)
+            return ops.dense_nhwc_bf16(ret.features, ret.indices, batch_size, ret.spatial_shape)
         ret = ret.dense()
         N, C_, D, H, W = ret.shape
         return ret.view(N, C_ * D, H, W)

@@ -449,6 +449,39 @@ def dense(features, indices, batch_size, shape):
     return DenseFunction.apply(features, indices.contiguous(), int(batch_size), to3(list(shape)))
 
 
+class DenseNHWCBf16Function(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, features, indices, batch_size, shape):
+        x = features.float().contiguous()
+        k, c = x.shape
+        d, h, w = shape
+        buf = torch.empty((batch_size, h, w, c * d), dtype=torch.bfloat16, device=x.device)
+        check(_lib.lib().lcf_dense_nhwc_bf16(_ptr(x), _ptr(indices), k, None, c, int(batch_size),
+                                             i3(shape), 1, _ptr(buf), _stream()))
+        ctx.save_for_backward(indices)
+        ctx.meta = (k, c, int(batch_size), list(shape), features.dtype)
+        return buf.permute(0, 3, 1, 2)  # [B, C*D, H, W], channels_last strides
+
+    @staticmethod
+    def backward(ctx, grad):
+        (indices,) = ctx.saved_tensors
+        k, c, b, shape, dt = ctx.meta
+        g = grad.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        df = torch.empty((k, c), dtype=torch.float32, device=g.device)
+        check(_lib.lib().lcf_dense_nhwc_bf16_bwd(_ptr(g), _ptr(indices), k, c, b, i3(shape),
+                                                 _ptr(df), _stream()))
+        return df.to(dt), None, None, None
+
+
+def dense_nhwc_bf16(features, indices, batch_size, shape):
+    """SparseConvTensor.dense() + view(N, C*D, H, W) (middle.py:206-209) produced directly as the
+    channels_last bf16 tensor the RPN's first convolution reads under bf16 autocast (values =
+    the fp32 dense tensor rounded to bf16; the gradient comes back in the same form)."""
+    _need_cuda(features, indices)
+    return DenseNHWCBf16Function.apply(features, indices.contiguous(), int(batch_size),
+                                       to3(list(shape)))
+
+
 # ------------------------------------------------------------------ VFE streaming kernels
 
 def vfe_mean(voxels, num_points, c):

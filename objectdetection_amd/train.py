@@ -23,6 +23,8 @@ class Detector(nn.Module):
         self.frontend = SparseFrontEnd(model, max_voxels=max_voxels)
         self.rpn = RPNV2(num_input_features=128)
         self.rpn_bf16 = rpn_bf16
+        if rpn_bf16:  # dense() lands in the RPN's input layout and dtype in one pass
+            self.frontend.middle_feature_extractor.dense_to = "rpn_bf16"
 
     def forward(self, clouds):
         x = self.frontend(clouds)
@@ -70,7 +72,10 @@ class TrainStep:
         self.net = randomize_(Detector(model), seed).to(device).train()
         self.net.rpn.to(memory_format=torch.channels_last)
         self.bucket = FlatGradAllReduce(self.net.parameters(), process_group)
-        self.opt = torch.optim.AdamW(self.net.parameters(), lr=lr, weight_decay=0.01)
+        # fused: one multi-tensor kernel per step instead of ~8 launches per parameter (78
+        # parameters: 0.8 ms of a 19 ms step); gradients share their parameter's layout (dist.py)
+        self.opt = torch.optim.AdamW(self.net.parameters(), lr=lr, weight_decay=0.01,
+                                     fused=torch.device(device).type == "cuda")
         self.gen = torch.Generator(device=device).manual_seed(seed)
 
     def __call__(self, clouds):

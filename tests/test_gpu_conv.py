@@ -353,6 +353,50 @@ def test_bf16x3_rejects_unsupported_widths(cuda):
         ops.weight_image_bf16x3(w)
 
 
+def test_dense_as_channels_last_bf16_equals_dense_view_cast(oracle, cuda):
+    """lcf_dense_nhwc_bf16 == dense() -> view(N, C*D, H, W) -> channels_last -> bfloat16 of the
+    reference's hand-off to the RPN (middle.py:206-209), bit for bit, forward and backward;
+    also against the oracle's dense()."""
+    rng = np.random.default_rng(5)
+    cs = []
+    for b in range(3):
+        c = _frame_coors(oracle, 30 + b, 4000)
+        c[:, 1] = c[:, 1] * 2 // 41
+        c[:, 2:] //= 8
+        c[:, 0] = b
+        cs.append(np.unique(c, axis=0))
+    coors = np.ascontiguousarray(np.concatenate(cs, 0).astype(np.int32))
+    shape = [2, 200, 176]
+    k, ch = coors.shape[0], 64
+    x = rng.standard_normal((k, ch)).astype(np.float32)
+    ref = oracle.dense(x, coors, 3, shape).reshape(3, ch * 2, 200, 176)
+    ct = torch.from_numpy(coors).to(cuda)
+    xa = torch.from_numpy(x).to(cuda).requires_grad_(True)
+    xb = torch.from_numpy(x).to(cuda).requires_grad_(True)
+    one = ops.dense_nhwc_bf16(xa, ct, 3, shape)
+    assert one.dtype == torch.bfloat16 and one.shape == (3, ch * 2, 200, 176)
+    assert one.is_contiguous(memory_format=torch.channels_last)
+    two = ops.dense(xb, ct, 3, shape).view(3, ch * 2, 200, 176).contiguous(
+        memory_format=torch.channels_last).to(torch.bfloat16)
+    assert torch.equal(one, two)
+    assert torch.equal(one.float().cpu(), torch.from_numpy(ref).to(torch.bfloat16).float())
+    g = torch.randn(one.shape, device=cuda).to(torch.bfloat16).contiguous(
+        memory_format=torch.channels_last)
+    one.backward(g)
+    two.backward(g)
+    assert torch.equal(xa.grad, xb.grad)
+    # rows outside the shape are dropped, and get no gradient
+    small = [2, 120, 90]
+    xc = torch.from_numpy(x).to(cuda).requires_grad_(True)
+    xd = torch.from_numpy(x).to(cuda).requires_grad_(True)
+    a = ops.dense_nhwc_bf16(xc, ct, 2, small)
+    b = ops.dense(xd, ct, 2, small).view(2, ch * 2, 120, 90).to(torch.bfloat16)
+    assert torch.equal(a, b)
+    a.float().sum().backward()
+    b.float().sum().backward()
+    assert torch.equal(xc.grad, xd.grad)
+
+
 def test_conv_with_dense_epilogue_rejects_what_it_cannot_do(cuda):
     from objectdetection_amd import _lib
     L = _lib.lib()

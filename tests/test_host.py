@@ -294,3 +294,33 @@ def test_dropin_registers_nms_module_names():
     assert N.rotate_iou_gpu_eval(np.zeros((0, 5), np.float32), np.zeros((3, 5), np.float32)).shape \
         == (0, 3)
     assert N.rotate_nms_gpu(np.zeros((0, 6), np.float32), 0.5) == []
+
+
+def test_flat_bucket_gradients_follow_the_parameter_layout():
+    """Gradient views of channels_last parameters have the parameter's strides (autograd's layout
+    contract), still alias the flat buffer, and hold the same values as an unbucketed run."""
+    import torch
+    from objectdetection_amd.dist import FlatGradAllReduce
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Conv2d(4, 8, 3, padding=1), torch.nn.ReLU(),
+                              torch.nn.Conv2d(8, 2, 3, padding=1))
+    ref = [p.detach().clone() for p in net.parameters()]
+    net.to(memory_format=torch.channels_last)
+    bucket = FlatGradAllReduce(net.parameters())
+    for p in net.parameters():
+        assert p.grad.stride() == p.stride()
+        assert p.grad.untyped_storage().data_ptr() == bucket.flat.untyped_storage().data_ptr()
+    x = torch.randn(2, 4, 5, 6)
+    net(x).square().sum().backward()
+    net2 = torch.nn.Sequential(torch.nn.Conv2d(4, 8, 3, padding=1), torch.nn.ReLU(),
+                               torch.nn.Conv2d(8, 2, 3, padding=1))
+    for p, r in zip(net2.parameters(), ref):
+        p.data.copy_(r)
+    net2(x).square().sum().backward()
+    for p, q in zip(net.parameters(), net2.parameters()):
+        assert torch.allclose(p.grad, q.grad, atol=1e-5)
+    assert float(bucket.flat.abs().sum()) > 0
+    bucket.zero()
+    assert all(float(p.grad.abs().sum()) == 0 for p in net.parameters())
+    with pytest.raises(ValueError):
+        FlatGradAllReduce([torch.nn.Parameter(torch.zeros(4, 6).t())])
