@@ -215,6 +215,13 @@ int lcf_indice_conv_fwd_dense(const float *feat, const float *wimg, const int *n
 int lcf_indice_conv_wgrad(const float *feat, const float *dout, const int *in_nbr, int k_in,
                           int kvol, int cin, int cout, float *dw, void *stream);
 
+/* dw [cin, cout] f32 = x^T dy over n dense rows (x [n, cin], dy [n, cout] row-major f32; cin,
+ * cout <= 128): weight gradient of the VFE's row-wise Linear layers (voxel_encoder.py:64, 127)
+ * -- called with x = dY and dy = X it yields nn.Linear's [out, in] layout.  fp32 MFMA, atomic
+ * accumulation over row chunks (not bit-reproducible); dw is zeroed inside. */
+int lcf_linear_wgrad(const float *x, const float *dy, int n, int cin, int cout, float *dw,
+                     void *stream);
+
 /* wgrad on the bf16 matrix cores (K dimension of one MFMA = 32 pairs).  planes = 1: operands
  * rounded to bf16, fp32 accumulation (BASELINE.json configs[2], tolerance 2e-2 of max |dw|);
  * planes = 2: operands split hi + lo as in lcf_indice_conv_fwd_bf16x3, three products per term

@@ -63,6 +63,7 @@ SYMBOLS = {
                                           c_int, _PI3, c_void_p, c_void_p]),
     "lcf_indice_conv_wgrad": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                       c_void_p, c_void_p]),
+    "lcf_linear_wgrad": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "lcf_indice_conv_wgrad_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                            c_int, c_int, c_void_p, c_void_p]),
     "lcf_dense": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, _PI3, c_int,

@@ -1277,8 +1277,11 @@ template <int CIN, int COUT>
 __global__ void __launch_bounds__(256)
 cv_wgrad_kernel(const float *__restrict__ feat, const float *__restrict__ dout,
                 const int *__restrict__ in_nbr, int k_in, int kvol, int cin, int cout,
-                int wg_rows, float *__restrict__ dw)
+                int wg_rows, float *__restrict__ dw, int ldf, int ldd, int ldw)
 {
+    // ldf / ldd / ldw: row strides (floats) of feat, dout and dw[o]: cin, cout, cout for the
+    // sparse conv; column blocks of wider matrices for lcf_linear_wgrad.  in_nbr == NULL: the
+    // identity table (dense rows: dw = feat^T dout).
     constexpr int MT = CIN / 16;  // row tiles of dW (ci)
     constexpr int NT = COUT / 16; // col tiles of dW (co)
     __shared__ float red[CIN * COUT];
@@ -1307,7 +1310,7 @@ cv_wgrad_kernel(const float *__restrict__ feat, const float *__restrict__ dout,
     // CONSECUTIVE channels of its rows -- one 16-byte load per operand at 64 channels, the 16
     // lanes of a quarter covering the whole row.  dW tile (m, n) therefore holds
     // ci = MT*row + m, co = NT*col + n (un-permuted when written out).
-    const bool vec_ok = (cin == CIN) && (cout == COUT);
+    const bool vec_ok = (cin == CIN) && (cout == COUT) && !(ldf & 3) && !(ldd & 3);
     auto fetch = [&](int cj, int cn, int c, int i, float *a, float *b) {
         const int s = 4 * i + q;
         const int j = __shfl(cj, s, 64);
@@ -1318,8 +1321,8 @@ cv_wgrad_kernel(const float *__restrict__ feat, const float *__restrict__ dout,
 #pragma unroll
         for (int nn = 0; nn < NT; ++nn) b[nn] = 0.f;
         if (ok) {
-            const float *fa = feat + (size_t)j * cin + MT * r16;
-            const float *fb = dout + (size_t)n * cout + NT * r16;
+            const float *fa = feat + (size_t)j * ldf + MT * r16;
+            const float *fb = dout + (size_t)n * ldd + NT * r16;
             if (vec_ok) {
                 if constexpr (MT % 4 == 0) {
 #pragma unroll
@@ -1358,7 +1361,7 @@ cv_wgrad_kernel(const float *__restrict__ feat, const float *__restrict__ dout,
 
     for (int blk = 0; blk < wg_rows / 4 / 64; ++blk) {
         const int row = wbeg + blk * 64 + lane;
-        const int nb = row < k_in ? in_nbr[(size_t)row * kvol + o] : -1;
+        const int nb = row < k_in ? (in_nbr ? in_nbr[(size_t)row * kvol + o] : row) : -1;
         const unsigned long long m = __ballot(nb >= 0);
         if (m == 0ull) continue; // wave-uniform
         any_total = true;
@@ -1404,10 +1407,10 @@ cv_wgrad_kernel(const float *__restrict__ feat, const float *__restrict__ dout,
         __syncthreads();
     }
     if (!any_s) return;
-    float *dwo = dw + (size_t)o * cin * cout;
+    float *dwo = dw + (size_t)o * cin * ldw;
     for (int e = tid; e < CIN * COUT; e += 256) {
         const int ci = e / COUT, co = e % COUT;
-        if (ci < cin && co < cout) atomicAdd(&dwo[(size_t)ci * cout + co], red[e]);
+        if (ci < cin && co < cout) atomicAdd(&dwo[(size_t)ci * ldw + co], red[e]);
     }
 }
 
@@ -1745,8 +1748,12 @@ extern "C" int lcf_indice_conv_fwd_dense(const float *feat, const float *wimg, c
 
 template <int CIN, int COUT>
 static int cv_launch_wgrad(const float *feat, const float *dout, const int *in_nbr, int k_in,
-                           int kvol, int cin, int cout, float *dw, hipStream_t st)
+                           int kvol, int cin, int cout, float *dw, hipStream_t st, int ldf = 0,
+                           int ldd = 0, int ldw = 0)
 {
+    if (!ldf) ldf = cin;
+    if (!ldd) ldd = cout;
+    if (!ldw) ldw = cout;
     // rows per workgroup (multiple of 256): ~3000 workgroups per launch, so that the per-
     // workgroup reduction and its atomics stay small next to the MFMA work
     long long want = ((long long)k_in * kvol + 2999) / 3000;
@@ -1756,7 +1763,7 @@ static int cv_launch_wgrad(const float *feat, const float *dout, const int *in_n
     const int nchunk = (k_in + wg_rows - 1) / wg_rows;
     const dim3 grid(((nchunk + 7) / 8) * 8 * kvol, 1);
     cv_wgrad_kernel<(CIN < 16 ? 16 : CIN), COUT><<<grid, 256, 0, st>>>(
-        feat, dout, in_nbr, k_in, kvol, cin, cout, wg_rows, dw);
+        feat, dout, in_nbr, k_in, kvol, cin, cout, wg_rows, dw, ldf, ldd, ldw);
     LCF_CHECK_LAUNCH();
     return LCF_OK;
 }
@@ -1817,4 +1824,36 @@ extern "C" int lcf_indice_conv_wgrad(const float *feat, const float *dout, const
     if (lcf_fill32(dw, 0u, (size_t)kvol * cin * cout * 4, st) != LCF_OK) return LCF_ERR_LAUNCH;
     if (k_in == 0) return LCF_OK;
     CV_DISPATCH(cv_launch_wgrad, feat, dout, in_nbr, k_in, kvol, cin, cout, dw, st);
+}
+
+static int cv_linear_wgrad_block(const float *x, int ldx, const float *dy, int ldy, int n, int cin,
+                                 int cout, float *dw, int ldw, hipStream_t st)
+{
+    int CIN = cv_pad_cin(cin), COUT = cv_pad_cout(cout);
+    if (CIN < 0 || COUT < 0 || CIN * COUT > 8192) return LCF_ERR_UNSUPPORTED;
+    CV_DISPATCH(cv_launch_wgrad, x, dy, nullptr, n, 1, cin, cout, dw, st, ldx, ldy, ldw);
+}
+
+// dw [cin, cout] = x^T dy over n dense rows: the weight gradient of a row-wise Linear layer (the
+// VFE's nn.Linear, voxel_encoder.py:64, 127; with x = dy and dy = x it is nn.Linear's own
+// [out, in] layout).  The reduction runs over ~10^5 rows into a matrix of at most 128 x 128, a
+// shape library GEMMs serve with a handful of workgroups; here it is the sparse wgrad kernel on
+// the identity table: thousands of row chunks, fp32 MFMA, one atomic add per chunk and element.
+extern "C" int lcf_linear_wgrad(const float *x, const float *dy, int n, int cin, int cout,
+                                float *dw, void *stream)
+{
+    if (n < 0 || cin <= 0 || cout <= 0 || !dw || (n > 0 && (!x || !dy))) return LCF_ERR_ARG;
+    if (cin > 128 || cout > 128) return LCF_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    if (lcf_fill32(dw, 0u, (size_t)cin * cout * 4, st) != LCF_OK) return LCF_ERR_LAUNCH;
+    if (n == 0) return LCF_OK;
+    int CIN = cv_pad_cin(cin), COUT = cv_pad_cout(cout);
+    if (CIN < 0 || COUT < 0) return LCF_ERR_UNSUPPORTED;
+    if (CIN * COUT <= 8192) return cv_linear_wgrad_block(x, cin, dy, cout, n, cin, cout, dw, cout, st);
+    // 128 x 128: two column halves of dy (the accumulators of one wave cover 8192 elements)
+    const int h = cout / 2;
+    if (cout & 1) return LCF_ERR_UNSUPPORTED;
+    int rc = cv_linear_wgrad_block(x, cin, dy, cout, n, cin, h, dw, cout, st);
+    if (rc != LCF_OK) return rc;
+    return cv_linear_wgrad_block(x, cin, dy + h, cout, n, cin, h, dw + h, cout, st);
 }

@@ -199,10 +199,10 @@ class _VFEBase(nn.Module):
         xp = aug[:, t - 1, :]                                      # a padding row where wp > 0
         neg = torch.finfo(aug.dtype).min
         for i, vfe in enumerate(layers):
-            yr = vfe.linear(xr)
+            yr = ops.tall_linear(vfe.linear, xr)
             c = yr.shape[1]
             if i == 0:
-                yp = vfe.linear(xp)
+                yp = ops.tall_linear(vfe.linear, xp)
                 scale, shift = self._bn_rows(vfe.norm, yr, n, yp, wp)
                 pad = F.relu(yp * scale + shift)
             else:
@@ -212,7 +212,7 @@ class _VFEBase(nn.Module):
             init = torch.where(has_pad, pad, torch.full_like(pad, neg))
             agg = _SegmentMax.apply(init, vk, yr)
             xr = torch.cat([yr, agg[vk]], dim=1)
-        yr = self.linear(xr)
+        yr = ops.tall_linear(self.linear, xr)
         scale, shift = self._bn_rows(self.norm, yr, n)
         yr = F.relu(yr * scale + shift)
         out = torch.zeros((k, yr.shape[1]), dtype=yr.dtype, device=yr.device)

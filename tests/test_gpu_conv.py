@@ -141,6 +141,39 @@ def test_matrix_core_wgrad_rejects_unsupported_shapes(cuda):
         ops.conv_wgrad(t, torch.zeros((8, 32), device=cuda), n, 27, 16, 32, planes=2)
 
 
+@pytest.mark.parametrize("cin,cout", [(7, 16), (16, 7), (32, 64), (64, 32), (128, 128),
+                                      (128, 64), (100, 120), (3, 5)])
+def test_linear_wgrad_equals_float64_product(cuda, cin, cout):
+    """lcf_linear_wgrad (weight gradient of the VFE's Linear layers: x^T dy over ~10^5 dense
+    rows) against the float64 product, within the fp32 tolerance; ragged row counts; through
+    TallLinearFunction: same outputs and gradients as nn.Linear."""
+    rng = np.random.default_rng(cin * 7 + cout)
+    for n in (1, 63, 257, 40001):
+        x = rng.standard_normal((n, cin)).astype(np.float32)
+        dy = rng.standard_normal((n, cout)).astype(np.float32)
+        ref = x.astype(np.float64).T @ dy.astype(np.float64)
+        got = ops.linear_wgrad(torch.from_numpy(x).to(cuda), torch.from_numpy(dy).to(cuda))
+        assert got.shape == (cin, cout)
+        assert rel_err(got.cpu().numpy(), ref) < RTOL
+    assert ops.linear_wgrad(torch.zeros((0, cin), device=cuda),
+                            torch.zeros((0, cout), device=cuda)).abs().sum().item() == 0
+    lin = torch.nn.Linear(cin, cout, bias=(cin % 2 == 0)).to(cuda)
+    xt = torch.from_numpy(x).to(cuda)
+    xa = xt.clone().requires_grad_(True)
+    xb = xt.clone().requires_grad_(True)
+    g = torch.from_numpy(dy).to(cuda)
+    ya = ops.tall_linear(lin, xa)
+    ya.backward(g)
+    ga = [p.grad.clone() for p in lin.parameters()]
+    lin.zero_grad()
+    yb = lin(xb)
+    yb.backward(g)
+    assert torch.equal(ya, yb)
+    assert torch.allclose(xa.grad, xb.grad, rtol=1e-5, atol=1e-5)
+    for a, p in zip(ga, lin.parameters()):
+        assert rel_err(a.cpu().numpy(), p.grad.cpu().numpy()) < RTOL
+
+
 def test_linearity_and_determinism_full_size(oracle, cuda):
     """Size-independent properties at the full BASELINE size (K ~ 40k rows, 64 channels)."""
     coors = _frame_coors(oracle, 0, 20000)
