@@ -106,6 +106,23 @@ class _SegmentMax(torch.autograd.Function):
         return g * (init == out), None, gy
 
 
+class _SegmentGather(torch.autograd.Function):
+    """x[seg] whose backward is a scatter-add (index_add_: atomics) instead of index_put_'s
+    sort-based accumulation (0.13 ms per call at 160k rows)."""
+
+    @staticmethod
+    def forward(ctx, x, seg):
+        ctx.save_for_backward(seg)
+        ctx.k = x.shape[0]
+        return x[seg]
+
+    @staticmethod
+    def backward(ctx, g):
+        (seg,) = ctx.saved_tensors
+        out = torch.zeros((ctx.k,) + g.shape[1:], dtype=g.dtype, device=g.device)
+        return out.index_add_(0, seg, g), None
+
+
 class VFELayer(nn.Module):
     def __init__(self, in_channels, out_channels, use_norm=True, name='vfe'):
         super().__init__()
@@ -211,7 +228,7 @@ class _VFEBase(nn.Module):
             yr = F.relu(yr * scale + shift)
             init = torch.where(has_pad, pad, torch.full_like(pad, neg))
             agg = _SegmentMax.apply(init, vk, yr)
-            xr = torch.cat([yr, agg[vk]], dim=1)
+            xr = torch.cat([yr, _SegmentGather.apply(agg, vk)], dim=1)
         yr = ops.tall_linear(self.linear, xr)
         scale, shift = self._bn_rows(self.norm, yr, n)
         yr = F.relu(yr * scale + shift)
