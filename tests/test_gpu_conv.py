@@ -380,6 +380,26 @@ def test_bf16x3_forward_matches_oracle_at_fp32_tolerance(oracle, cuda, cin, cout
         L.lcf_set_option(_lib.OPT_CONV_IMPL, 0)
 
 
+def test_bf16x3_identity_table_is_a_row_wise_linear_layer(cuda):
+    """nbr = NULL, kvol = 1 (the row-wise linear form of the fp32 entry point) on split operands:
+    against the float64 product, ragged row counts, device-side count below the capacity."""
+    rng = np.random.default_rng(11)
+    for n, cin, cout in ((1, 32, 32), (77, 64, 128), (5000, 128, 64)):
+        x = rng.standard_normal((n, cin)).astype(np.float32)
+        w = (rng.standard_normal((1, cin, cout)) / np.sqrt(cin)).astype(np.float32)
+        ref = x.astype(np.float64) @ w[0].astype(np.float64)
+        xt, wt = torch.from_numpy(x).to(cuda), torch.from_numpy(w).to(cuda)
+        img = ops.weight_image_bf16x3(wt)
+        out = ops.conv_forward_bf16x3(xt, img, None, n, 1, cin, cout)
+        assert rel_err(out.cpu().numpy(), ref) < 2e-5
+        if n > 10:
+            kd = torch.tensor([n - 9], dtype=torch.int32, device=cuda)
+            part = torch.full((n, cout), 7.0, device=cuda)
+            ops.conv_forward_bf16x3(xt, img, None, n, 1, cin, cout, n_rows_dev=kd, out=part)
+            assert torch.equal(part[:n - 9], out[:n - 9])
+            assert bool((part[n - 9:] == 7.0).all())
+
+
 def test_bf16x3_rejects_unsupported_widths(cuda):
     w = torch.zeros((27, 16, 32), device=cuda)
     with pytest.raises(RuntimeError):
