@@ -229,13 +229,15 @@ _CONV_MATH = ["f32"]
 
 
 class conv_math:
-    """Context manager / setter for the MFMA operand type of the TRAINING indice_conv
-    (forward + dgrad through ``indice_conv``): "f32" (default, exact fp32 MFMA) or "bf16"
-    (bf16 operands, fp32 accumulate; layers whose channels are not 32/64/128 stay fp32)."""
+    """Context manager / setter for the MFMA operand type of indice_conv: "f32" (default, fp32
+    MFMA); "bf16" for TRAINING (forward + dgrad through ``indice_conv`` with bf16 operands, fp32
+    accumulate, tolerance 2e-2); "bf16x3" for INFERENCE (the no-grad forward of the sparse conv
+    modules with split hi + lo bf16 operands, fp32 tolerance; training under it stays fp32).
+    Layers whose channels are not 32/64/128 stay fp32 in every mode."""
 
     def __init__(self, mode):
-        if mode not in ("f32", "bf16"):
-            raise ValueError("conv math mode must be 'f32' or 'bf16'")
+        if mode not in ("f32", "bf16", "bf16x3"):
+            raise ValueError("conv math mode must be 'f32', 'bf16' or 'bf16x3'")
         self.mode, self.prev = mode, None
 
     def __enter__(self):
@@ -245,6 +247,10 @@ class conv_math:
 
     def __exit__(self, *exc):
         _CONV_MATH[0] = self.prev
+
+
+def get_conv_math():
+    return _CONV_MATH[0]
 
 
 def set_conv_math(mode):

@@ -117,15 +117,13 @@ class SparseConvolution(SparseModule):
                 shift = b * _scale + _shift if _scale is not None else (
                     b + _shift if _shift is not None else b)
             x = features if features.dtype == torch.float32 else features.float()
-            out = ops.conv_forward(x, self._weight_image(), rb.out_nbr, rb.k_out, rb.kvol,
-                                   self.in_channels, self.out_channels, _scale,
-                                   None if shift is None else shift.contiguous(), _relu)
+            out = self._inference_forward(x, rb, _scale,
+                                          None if shift is None else shift.contiguous(), _relu)
             out = out.to(features.dtype)
         elif not torch.is_grad_enabled():
             x = features if features.dtype == torch.float32 else features.float()
             shift = None if self.bias is None else self.bias.float().contiguous()
-            out = ops.conv_forward(x, self._weight_image(), rb.out_nbr, rb.k_out, rb.kvol,
-                                   self.in_channels, self.out_channels, None, shift, False)
+            out = self._inference_forward(x, rb, None, shift, False)
             out = out.to(features.dtype)
         else:
             out = ops.indice_conv(features, self.weight, rb)
@@ -136,14 +134,26 @@ class SparseConvolution(SparseModule):
         out_tensor.grid = input.grid
         return out_tensor
 
-    def _weight_image(self):
-        """MFMA weight image, cached until the parameter is modified in place or replaced."""
+    def _inference_forward(self, x, rb, scale, shift, relu):
+        """No-grad forward: fp32 MFMA, or -- under ``ops.conv_math("bf16x3")`` and for 32 / 64 /
+        128 channels on both sides -- split bf16 operands at fp32 tolerance (include/lcf.h)."""
+        cin, cout = self.in_channels, self.out_channels
+        if ops.get_conv_math() == "bf16x3" and ops.bf16_supported(cin, cout):
+            return ops.conv_forward_bf16x3(x, self._weight_image(True), rb.out_nbr, rb.k_out,
+                                           rb.kvol, cin, cout, scale, shift, relu)
+        return ops.conv_forward(x, self._weight_image(), rb.out_nbr, rb.k_out, rb.kvol, cin, cout,
+                                scale, shift, relu)
+
+    def _weight_image(self, split=False):
+        """MFMA weight image (split: the two-plane bf16x3 image), cached until the parameter is
+        modified in place or replaced."""
         w = self.weight
         tag = (w.data_ptr(), w._version, w.device, w.dtype)
-        cache = getattr(self, "_wimg", None)
+        name = "_wimg3" if split else "_wimg"
+        cache = getattr(self, name, None)
         if cache is None or cache[0] != tag:
-            cache = (tag, ops.weight_image(w))
-            object.__setattr__(self, "_wimg", cache)
+            cache = (tag, (ops.weight_image_bf16x3 if split else ops.weight_image)(w))
+            object.__setattr__(self, name, cache)
         return cache[1]
 
 

@@ -154,3 +154,22 @@ def test_engine_bf16x3_stays_inside_the_fp32_feature_tolerance(cuda, name):
             assert torch.equal(eng.forward(c), out)
     with pytest.raises(ValueError):
         model.engine(calib=_clouds(cuda, [0], 3000), conv_math="bf16")
+
+
+def test_module_path_bf16x3_equals_engine_bf16x3(cuda):
+    """ops.conv_math("bf16x3") puts the module-by-module (spconv API) inference path on the same
+    split-operand kernels as FrameEngine(conv_math="bf16x3"): same kernels pinned to one wave set
+    -> bit-identical; inside the fp32 tolerance of the fp32 module path."""
+    from objectdetection_amd import ops
+    model = randomize_(SparseFrontEnd("M1").eval(), 0).to(cuda)
+    c = _clouds(cuda, [4], 15000)[0]
+    with torch.no_grad(), one_wave_set():
+        eng = model.engine(calib=[c], conv_math="bf16x3")
+        out = eng.forward(c).clone()
+        ref32 = model([c])
+        with ops.conv_math("bf16x3"):
+            ref3 = model([c])
+        assert ops.get_conv_math() == "f32"
+    assert torch.equal(out, ref3)
+    err = ((ref3 - ref32).abs().max() / ref32.abs().max()).item()
+    assert 0 < err < 1e-4
