@@ -30,6 +30,27 @@ def test_frontend_matches_cpu_pipeline(cuda, name):
     assert (out != 0).any()
 
 
+@pytest.mark.parametrize("name", ["M1", "M2", "M3"])
+def test_frontend_bf16x3_matches_cpu_pipeline_at_fp32_tolerance(cuda, name):
+    """The whole front end with its wide sparse convs on split bf16 operands
+    (ops.conv_math("bf16x3")) against the CPU pipeline: inside the north star's 1e-4, and its
+    distance from the fp32 path reported by the assertion message."""
+    from oracle import cpu_pipeline
+    from objectdetection_amd import ops
+    pts = [synth.vkitti_frame(5, 20000)]
+    ref = cpu_pipeline.frontend_forward(randomize_(SparseFrontEnd(name).eval(), 4), pts)
+    model = randomize_(SparseFrontEnd(name).eval(), 4).to(cuda)
+    with torch.no_grad():
+        c = [torch.from_numpy(p).to(cuda) for p in pts]
+        out32 = model(c)
+        with ops.conv_math("bf16x3"):
+            out3 = model(c)
+    e32, e3 = rel_err(out32.cpu().numpy(), ref), rel_err(out3.cpu().numpy(), ref)
+    assert e32 < RTOL and e3 < RTOL, (e32, e3)
+    assert e3 < 5e-5, (e32, e3)
+    assert not torch.equal(out3, out32)  # the mode is really in effect
+
+
 def test_frontend_batch2_and_m3(cuda):
     from oracle import cpu_pipeline
     pts = [synth.vkitti_frame(1, 20000), synth.vkitti_frame(2, 12000)]
