@@ -246,6 +246,22 @@ int lcf_dense(const float *feat, const int *coors, int k, const int *k_dev, int 
 int lcf_dense_bwd(const float *dout, const int *coors, int k, int c, int batch,
                   const int shape[3], float *dfeat, void *stream);
 
+/* VFE training, the tail of a layer after the Linear and the batch statistics
+ * (voxel_encoder.py:69-80, 134-139, over the real points only): y [p,c] = relu(x * scale + shift)
+ * and agg[seg[r], :] = max(agg[seg[r], :], y[r, :]) in one pass.  seg [p] int32 voxel id of each
+ * row; agg [k,c] arrives initialised (values >= 0, or any negative number for "no contribution")
+ * and every seg[r] must lie in [0, k).  c % 4 == 0, c <= 128.  _bwd: with
+ * g = [y > 0] * (gy + [y == agg[seg]] * gagg[seg]) (gy may be NULL = zeros):
+ * dx = g * scale, dscale = sum_r g * x, dshift = sum_r g (fixed-order sums, deterministic).
+ * Workspace: lcf_bn_workspace_bytes(p, c). */
+int lcf_vfe_affine_relu_segmax_fwd(const float *x, int p, int c, const float *scale,
+                                   const float *shift, const int *seg, float *y, float *agg,
+                                   void *stream);
+int lcf_vfe_affine_relu_segmax_bwd(const float *x, const float *y, const float *agg,
+                                   const float *gy, const float *gagg, const int *seg, int p,
+                                   int c, const float *scale, float *dx, float *dscale,
+                                   float *dshift, void *ws, size_t ws_bytes, void *stream);
+
 /* dense() handed to the RPN's first convolution without a layout or dtype pass (SURVEY.md
  * section 8f-1; middle.py:206-209 + rpn.py:486-495 under bf16 autocast): the [B, C*D, H, W] view
  * as channels_last bf16, memory [B, H, W, C*D], element (b, c, z, y, x) at

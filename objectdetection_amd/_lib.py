@@ -70,6 +70,11 @@ SYMBOLS = {
                           c_void_p, c_void_p]),
     "lcf_dense_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, _PI3, c_void_p,
                               c_void_p]),
+    "lcf_vfe_affine_relu_segmax_fwd": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p,
+                                               c_void_p, c_void_p, c_void_p, c_void_p]),
+    "lcf_vfe_affine_relu_segmax_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                               c_void_p, c_int, c_int, c_void_p, c_void_p,
+                                               c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "lcf_dense_nhwc_bf16": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, _PI3,
                                     c_int, c_void_p, c_void_p]),
     "lcf_dense_nhwc_bf16_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, _PI3, c_void_p,

@@ -275,3 +275,140 @@ extern "C" int lcf_bn_relu_bwd(const float *x, const float *y, const float *dy, 
     LCF_CHECK_LAUNCH();
     return LCF_OK;
 }
+
+// ------------------------------------------------------------------------------------------
+// VFE training (voxel_encoder.py:69-80, 134-139 over the real points only, see
+// objectdetection_amd/voxel_encoder.py::_forward_compact): per layer, after the Linear and the
+// batch statistics, y = relu(x * scale + shift) and the per-voxel maximum agg[seg[r]] =
+// max(agg[seg[r]], y[r]) -- one pass here instead of mul / add / relu / scatter-max, and one pass
+// plus a column sum backward instead of nine elementwise / reduction launches.  agg arrives
+// initialised (what the voxel's padding rows contribute, or a negative sentinel); y >= 0, so the
+// maximum is an integer max on the float bits (order-independent: deterministic).
+__global__ void __launch_bounds__(BN_BLOCK)
+vfe_ars_fwd_kernel(const float *__restrict__ x, int p, int c, int rows_per_block,
+                   const float *__restrict__ scale, const float *__restrict__ shift,
+                   const int *__restrict__ seg, float *__restrict__ y, float *__restrict__ agg)
+{
+    const BnMap m = bn_map(c);
+    if (m.rl >= m.RL) return;
+    const float4 a = reinterpret_cast<const float4 *>(scale)[m.c4];
+    const float4 b = reinterpret_cast<const float4 *>(shift)[m.c4];
+    const int r0 = blockIdx.x * rows_per_block;
+    const int r1 = min(p, r0 + rows_per_block);
+    for (int r = r0 + m.rl; r < r1; r += m.RL) {
+#pragma clang fp contract(off)
+        float4 v = reinterpret_cast<const float4 *>(x + (size_t)r * c)[m.c4];
+        // product and sum rounded separately (no fma contraction): the values of the torch
+        // composition mul -> add -> relu, bit for bit
+        const float4 t = make_float4(v.x * a.x, v.y * a.y, v.z * a.z, v.w * a.w);
+        v.x = fmaxf(t.x + b.x, 0.f);
+        v.y = fmaxf(t.y + b.y, 0.f);
+        v.z = fmaxf(t.z + b.z, 0.f);
+        v.w = fmaxf(t.w + b.w, 0.f);
+        reinterpret_cast<float4 *>(y + (size_t)r * c)[m.c4] = v;
+        int *dst = reinterpret_cast<int *>(agg + (size_t)seg[r] * c) + m.c4 * 4;
+        atomicMax(dst + 0, __float_as_int(v.x));
+        atomicMax(dst + 1, __float_as_int(v.y));
+        atomicMax(dst + 2, __float_as_int(v.z));
+        atomicMax(dst + 3, __float_as_int(v.w));
+    }
+}
+
+// g = [y > 0] * (gy + [y == agg[seg]] * gagg[seg]);  dx = g * scale;  partial sums of g, g * x
+__global__ void __launch_bounds__(BN_BLOCK)
+vfe_ars_bwd_kernel(const float *__restrict__ x, const float *__restrict__ y,
+                   const float *__restrict__ agg, const float *__restrict__ gy,
+                   const float *__restrict__ gagg, const int *__restrict__ seg, int p, int c,
+                   int rows_per_block, const float *__restrict__ scale, float *__restrict__ dx,
+                   float *__restrict__ parts)
+{
+    __shared__ __align__(16) float lds[BN_BLOCK * 8];
+    const BnMap m = bn_map(c);
+    const int r0 = blockIdx.x * rows_per_block;
+    const int r1 = min(p, r0 + rows_per_block);
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f), q = s;
+    if (m.rl < m.RL) {
+        const float4 a = reinterpret_cast<const float4 *>(scale)[m.c4];
+        for (int r = r0 + m.rl; r < r1; r += m.RL) {
+            const float4 xv = reinterpret_cast<const float4 *>(x + (size_t)r * c)[m.c4];
+            const float4 yv = reinterpret_cast<const float4 *>(y + (size_t)r * c)[m.c4];
+            const size_t so = (size_t)seg[r] * c;
+            const float4 av = reinterpret_cast<const float4 *>(agg + so)[m.c4];
+            const float4 ga = reinterpret_cast<const float4 *>(gagg + so)[m.c4];
+            float4 g = gy ? reinterpret_cast<const float4 *>(gy + (size_t)r * c)[m.c4]
+                          : make_float4(0.f, 0.f, 0.f, 0.f);
+            g.x = yv.x > 0.f ? g.x + (yv.x == av.x ? ga.x : 0.f) : 0.f;
+            g.y = yv.y > 0.f ? g.y + (yv.y == av.y ? ga.y : 0.f) : 0.f;
+            g.z = yv.z > 0.f ? g.z + (yv.z == av.z ? ga.z : 0.f) : 0.f;
+            g.w = yv.w > 0.f ? g.w + (yv.w == av.w ? ga.w : 0.f) : 0.f;
+            s.x += g.x; s.y += g.y; s.z += g.z; s.w += g.w;
+            q.x += g.x * xv.x; q.y += g.y * xv.y; q.z += g.z * xv.z; q.w += g.w * xv.w;
+            reinterpret_cast<float4 *>(dx + (size_t)r * c)[m.c4] =
+                make_float4(g.x * a.x, g.y * a.y, g.z * a.z, g.w * a.w);
+        }
+    }
+    bn_block_reduce(m, c, s, q, lds, parts + (size_t)blockIdx.x * 2 * c);
+}
+
+// dshift[e] = sum of the partials of column e, dscale[e] = of column c + e; one wave per column
+__global__ void __launch_bounds__(64)
+vfe_ars_finalize_kernel(const float *__restrict__ parts, int nparts, int c,
+                        float *__restrict__ dscale, float *__restrict__ dshift)
+{
+    const int e = blockIdx.x;
+    double s = 0.0;
+    for (int q = threadIdx.x; q < nparts; q += 64) s += (double)parts[(size_t)q * 2 * c + e];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) s += __shfl_down(s, d, 64);
+    if (threadIdx.x == 0) {
+        if (e < c)
+            dshift[e] = (float)s;
+        else
+            dscale[e - c] = (float)s;
+    }
+}
+
+extern "C" int lcf_vfe_affine_relu_segmax_fwd(const float *x, int p, int c, const float *scale,
+                                              const float *shift, const int *seg, float *y,
+                                              float *agg, void *stream)
+{
+    int rc = bn_check(p, c);
+    if (rc) return rc;
+    if (!x || !scale || !shift || !seg || !y || !agg) return LCF_ERR_ARG;
+    if (((uintptr_t)x & 15) || ((uintptr_t)y & 15) || ((uintptr_t)scale & 15) ||
+        ((uintptr_t)shift & 15) || ((uintptr_t)agg & 15))
+        return LCF_ERR_ARG;
+    int rpb, np;
+    bn_partition(p, &rpb, &np);
+    vfe_ars_fwd_kernel<<<np, BN_BLOCK, 0, (hipStream_t)stream>>>(x, p, c, rpb, scale, shift, seg,
+                                                                 y, agg);
+    LCF_CHECK_LAUNCH();
+    return LCF_OK;
+}
+
+extern "C" int lcf_vfe_affine_relu_segmax_bwd(const float *x, const float *y, const float *agg,
+                                              const float *gy, const float *gagg, const int *seg,
+                                              int p, int c, const float *scale, float *dx,
+                                              float *dscale, float *dshift, void *ws,
+                                              size_t ws_bytes, void *stream)
+{
+    int rc = bn_check(p, c);
+    if (rc) return rc;
+    if (!x || !y || !agg || !gagg || !seg || !scale || !dx || !dscale || !dshift || !ws)
+        return LCF_ERR_ARG;
+    if (((uintptr_t)x & 15) || ((uintptr_t)y & 15) || ((uintptr_t)agg & 15) ||
+        ((uintptr_t)gy & 15) || ((uintptr_t)gagg & 15) || ((uintptr_t)scale & 15) ||
+        ((uintptr_t)dx & 15))
+        return LCF_ERR_ARG;
+    if (ws_bytes < lcf_bn_workspace_bytes(p, c)) return LCF_ERR_WORKSPACE;
+    int rpb, np;
+    bn_partition(p, &rpb, &np);
+    hipStream_t st = (hipStream_t)stream;
+    float *parts = (float *)ws;
+    vfe_ars_bwd_kernel<<<np, BN_BLOCK, 0, st>>>(x, y, agg, gy, gagg, seg, p, c, rpb, scale, dx,
+                                                parts);
+    LCF_CHECK_LAUNCH();
+    vfe_ars_finalize_kernel<<<2 * c, 64, 0, st>>>(parts, np, c, dscale, dshift);
+    LCF_CHECK_LAUNCH();
+    return LCF_OK;
+}

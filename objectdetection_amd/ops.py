@@ -633,6 +633,55 @@ class BNReLUFunction(torch.autograd.Function):
         return dx, dg, db, None, None
 
 
+class AffineReluSegMaxFunction(torch.autograd.Function):
+    """(y, agg) = (relu(x * scale + shift), per-segment max of y on top of ``init``) -- the tail of
+    a VFE layer in training (lcf_vfe_affine_relu_segmax_fwd / _bwd).  The gradient of the maximum
+    goes to every element that attains it, as voxel_encoder._SegmentMax does."""
+
+    @staticmethod
+    def forward(ctx, x, scale, shift, init, seg):
+        x = x.contiguous()
+        scale, shift = scale.contiguous(), shift.contiguous()
+        p, c = x.shape
+        y = torch.empty_like(x)
+        agg = init.clone(memory_format=torch.contiguous_format)
+        check(_lib.lib().lcf_vfe_affine_relu_segmax_fwd(_ptr(x), p, c, _ptr(scale), _ptr(shift),
+                                                        _ptr(seg), _ptr(y), _ptr(agg), _stream()))
+        ctx.save_for_backward(x, y, agg, scale, init, seg)
+        ctx.set_materialize_grads(False)
+        return y, agg
+
+    @staticmethod
+    def backward(ctx, gy, gagg):
+        x, y, agg, scale, init, seg = ctx.saved_tensors
+        p, c = x.shape
+        if gagg is None:
+            gagg = torch.zeros_like(agg)
+        gagg = gagg.contiguous()
+        gy = None if gy is None else gy.contiguous()
+        L = _lib.lib()
+        dx = torch.empty_like(x)
+        dscale = torch.empty_like(scale)
+        dshift = torch.empty_like(scale)
+        ws = _ws(L.lcf_bn_workspace_bytes(p, c), x.device)
+        check(L.lcf_vfe_affine_relu_segmax_bwd(_ptr(x), _ptr(y), _ptr(agg), _ptr(gy), _ptr(gagg),
+                                               _ptr(seg), p, c, _ptr(scale), _ptr(dx),
+                                               _ptr(dscale), _ptr(dshift), _ptr(ws), ws.numel(),
+                                               _stream()))
+        dinit = gagg * (init == agg) if ctx.needs_input_grad[3] else None
+        return dx, dscale, dshift, dinit, None
+
+
+def affine_relu_segmax_supported(x):
+    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.shape[0] > 0
+            and x.shape[1] % 4 == 0 and x.shape[1] <= 128)
+
+
+def affine_relu_segmax(x, scale, shift, init, seg):
+    """x [p,c], scale / shift [c], init [k,c], seg [p] int32 (voxel of each row) -> (y, agg)."""
+    return AffineReluSegMaxFunction.apply(x, scale, shift, init, seg)
+
+
 def bn_relu_train(norm, x, relu=True):
     """nn.BatchNorm1d `norm` in training mode (+ ReLU) on x [K, C]: the fused kernels, then the
     running-statistics update nn.BatchNorm1d would have done (unbiased variance, momentum)."""

@@ -215,6 +215,9 @@ class _VFEBase(nn.Module):
         xr = aug.reshape(n, -1)[rows]
         xp = aug[:, t - 1, :]                                      # a padding row where wp > 0
         neg = torch.finfo(aug.dtype).min
+        # relu(y * scale + shift) + per-voxel max and their backward as one kernel pair (liblcf)
+        fused = ops.affine_relu_segmax_supported(xr) and xr.shape[0] > 0
+        vk32 = vk.int() if fused else None
         for i, vfe in enumerate(layers):
             yr = ops.tall_linear(vfe.linear, xr)
             c = yr.shape[1]
@@ -225,14 +228,19 @@ class _VFEBase(nn.Module):
             else:
                 scale, shift = self._bn_rows(vfe.norm, yr, n)
                 pad = F.relu(shift).expand(k, c)
-            yr = F.relu(yr * scale + shift)
             init = torch.where(has_pad, pad, torch.full_like(pad, neg))
-            agg = _SegmentMax.apply(init, vk, yr)
+            if fused and c % 4 == 0 and c <= 128:
+                yr, agg = ops.affine_relu_segmax(yr, scale, shift, init, vk32)
+            else:
+                yr = F.relu(yr * scale + shift)
+                agg = _SegmentMax.apply(init, vk, yr)
             xr = torch.cat([yr, _SegmentGather.apply(agg, vk)], dim=1)
         yr = ops.tall_linear(self.linear, xr)
         scale, shift = self._bn_rows(self.norm, yr, n)
-        yr = F.relu(yr * scale + shift)
         out = torch.zeros((k, yr.shape[1]), dtype=yr.dtype, device=yr.device)
+        if fused and yr.shape[1] % 4 == 0 and yr.shape[1] <= 128:
+            return ops.affine_relu_segmax(yr, scale, shift, out, vk32)[1]
+        yr = F.relu(yr * scale + shift)
         return _SegmentMax.apply(out, vk, yr)
 
     def _fused_lin(self, layers):

@@ -174,6 +174,41 @@ def test_linear_wgrad_equals_float64_product(cuda, cin, cout):
         assert rel_err(a.cpu().numpy(), p.grad.cpu().numpy()) < RTOL
 
 
+@pytest.mark.parametrize("c", [16, 64, 128])
+def test_vfe_affine_relu_segmax_equals_torch_composition(cuda, c):
+    """lcf_vfe_affine_relu_segmax_fwd / _bwd (the tail of a VFE layer in training) against
+    relu(x * scale + shift) followed by voxel_encoder._SegmentMax in torch: outputs bit-identical
+    (same fp32 operations; max is order-independent), gradients of x / scale / shift / init to
+    fp32 summation order; voxels whose initial value wins; gy absent (the final layer)."""
+    from objectdetection_amd.voxel_encoder import _SegmentMax
+    g = torch.Generator(device="cuda").manual_seed(c)
+    k, p = 3000, 7001
+    seg = torch.sort(torch.randint(0, k, (p,), device=cuda, generator=g)).values
+    x = torch.randn((p, c), device=cuda, generator=g)
+    scale = torch.rand((c,), device=cuda, generator=g) + 0.5
+    shift = torch.randn((c,), device=cuda, generator=g) * 0.3
+    pad = torch.relu(torch.randn((k, c), device=cuda, generator=g))
+    has = torch.rand((k, 1), device=cuda, generator=g) < 0.5
+    init = torch.where(has, pad, torch.full_like(pad, torch.finfo(torch.float32).min))
+    gy = torch.randn((p, c), device=cuda, generator=g)
+    ga = torch.randn((k, c), device=cuda, generator=g)
+    for with_gy in (True, False):
+        leaves = [t.clone().requires_grad_(True) for t in (x, scale, shift, init)]
+        ref_leaves = [t.clone().requires_grad_(True) for t in (x, scale, shift, init)]
+        y, agg = ops.affine_relu_segmax(*leaves, seg.int())
+        yr = torch.relu(ref_leaves[0] * ref_leaves[1] + ref_leaves[2])
+        aggr = _SegmentMax.apply(ref_leaves[3], seg, yr)
+        assert torch.equal(y, yr) and torch.equal(agg, aggr)
+        if with_gy:
+            torch.autograd.backward([y, agg], [gy, ga])
+            torch.autograd.backward([yr, aggr], [gy, ga])
+        else:
+            agg.backward(ga)
+            aggr.backward(ga)
+        for a, b in zip(leaves, ref_leaves):
+            assert rel_err(a.grad.cpu().numpy(), b.grad.cpu().numpy()) < 1e-5
+
+
 def test_linearity_and_determinism_full_size(oracle, cuda):
     """Size-independent properties at the full BASELINE size (K ~ 40k rows, 64 channels)."""
     coors = _frame_coors(oracle, 0, 20000)
