@@ -150,7 +150,7 @@ def main():
     ap.add_argument("--train-batch", type=int, default=8, help="frames per rank per step")
     ap.add_argument("--inflight", type=int, default=1,
                     help="independent frames in flight (one FrameEngine + stream each)")
-    ap.add_argument("--conv-math", default="f32", choices=["f32", "bf16x3"],
+    ap.add_argument("--conv-math", default="f32", choices=["f32", "bf16x3", "bf16x8"],
                     help="operand form of the 32/64/128-channel sparse convs in the timed path: "
                          "fp32 MFMA (the headline) or split bf16 operands (lcf.h: bf16x3)")
     ap.add_argument("--no-alt", action="store_true",
@@ -237,26 +237,32 @@ def main():
         assert out.shape[1:] == (128, 200, 176) or args.model == "M3", out.shape
         roof = dominant_kernel_roofline(model, clouds[0]) if rank == 0 and args.model != "M3" \
             else None
-        # secondary line (never `value`): the same frames through an engine whose wide sparse
-        # convs run split-operand bf16x3 math, with its error against the fp32 module path
+        # secondary lines (never `value`): the same frames through engines whose wide sparse
+        # convs run split-operand math on the bf16 matrix cores -- "bf16x8" (three exact planes,
+        # fp32-grade) and "bf16x3" (two planes, ~2e-5) -- with their error against the fp32
+        # module path
         alt = None
         if (world == 1 and not args.eager and not args.no_alt and args.conv_math == "f32"
                 and args.model != "M3"):
-            eng3 = model.engine(calib=clouds, conv_math="bf16x3")
-            for i in range(args.warmup):
-                eng3.forward(clouds[i % len(clouds)])
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for i in range(args.steps):
-                out3 = eng3.forward(clouds[i % len(clouds)])
-            torch.cuda.synchronize()
-            el3 = time.perf_counter() - t1
-            eng3.check()
-            err3 = ((out3 - ref).abs().max() / ref.abs().max()).item()
-            assert err3 < 1e-4, f"bf16x3 engine outside the fp32 feature tolerance: {err3}"
-            alt = {"conv_math": "bf16x3", "value": round(args.steps / el3, 2),
-                   "unit": "frames/s", "ms_per_step": round(el3 / args.steps * 1e3, 4),
-                   "max_err_vs_f32_rel_to_max": float(f"{err3:.3g}"), "tolerance": 1e-4}
+            alt = []
+            for cm in ("bf16x8", "bf16x3"):
+                eng3 = model.engine(calib=clouds, conv_math=cm)
+                for i in range(args.warmup):
+                    eng3.forward(clouds[i % len(clouds)])
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for i in range(args.steps):
+                    out3 = eng3.forward(clouds[i % len(clouds)])
+                torch.cuda.synchronize()
+                el3 = time.perf_counter() - t1
+                eng3.check()
+                err3 = ((out3 - ref).abs().max() / ref.abs().max()).item()
+                assert err3 < 1e-4, f"{cm} engine outside the fp32 feature tolerance: {err3}"
+                alt.append({"conv_math": cm, "value": round(args.steps / el3, 2),
+                            "unit": "frames/s", "ms_per_step": round(el3 / args.steps * 1e3, 4),
+                            "max_err_vs_f32_rel_to_max": float(f"{err3:.3g}"),
+                            "tolerance": 1e-4})
+                del eng3
 
     train = train_measurement(args, dev, rank, world, dist, barrier) if args.train_steps > 0 \
         and args.model != "M3" else None
@@ -268,7 +274,9 @@ def main():
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if args.conv_math == "f32" else "bf16x3 (f32 = hi + lo, f32 accumulate)",
+            "dtype": {"f32": "f32", "bf16x3": "bf16x3 (f32 = hi + lo, f32 accumulate)",
+                      "bf16x8": "bf16x8 (f32 = hi + mid + lo exactly, f32 accumulate)"}[
+                          args.conv_math],
             "data": "synthetic",
             "config": {"workload": f"{args.model}: one {args.points}-point "
                                    f"{'Virtual-KITTI' if args.shape == 'vkitti' else 'SYNTHIA'}-shaped "

@@ -199,6 +199,19 @@ int lcf_indice_conv_fwd_bf16x3(const float *feat, const void *wimg_bf16x3, const
                                const float *scale, const float *shift, int relu, float *out,
                                const int *dense_coors, int batch, const int shape[3],
                                void *stream);
+/* Three-plane form of the same ("bf16x8"): x = hi + mid + lo exactly (three bf16 planes, 8 + 8 + 8
+ * significand bits) and the eight products down to 2^-24 |a||w| -- what is dropped (lo*lo, 2^-32)
+ * is far below the rounding of fp32 operands' own products, so results are fp32-grade (measured:
+ * the same distance from the float64 oracle as lcf_indice_conv_fwd), at half the matrix-pipe
+ * cycles of the fp32 MFMA.  Image: 3 * kvol*cin*cout 2-byte elements.  Same arguments, shapes
+ * and dense-target option as the bf16x3 pair. */
+int lcf_weight_image_bf16x8(const float *w, int kvol, int cin, int cout, int transpose,
+                            void *img, void *stream);
+int lcf_indice_conv_fwd_bf16x8(const float *feat, const void *wimg_bf16x8, const int *nbr,
+                               int k_out, const int *k_out_dev, int kvol, int cin, int cout,
+                               const float *scale, const float *shift, int relu, float *out,
+                               const int *dense_coors, int batch, const int shape[3],
+                               void *stream);
 /* fwd with SparseConvTensor.dense() (second/pytorch/models/middle.py:206, right after the last
  * SparseConv3d + BatchNorm1d + ReLU of the stack, :186-192) fused into its epilogue: instead of
  * out[row,:] the result lands in dense[b, :, z, y, x] of a [batch, cout, D, H, W] f32 tensor,

@@ -58,6 +58,11 @@ SYMBOLS = {
     "lcf_indice_conv_fwd_bf16x3": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int,
                                            c_int, c_int, c_void_p, c_void_p, c_int, c_void_p,
                                            c_void_p, c_int, _PI3, c_void_p]),
+    "lcf_weight_image_bf16x8": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p,
+                                        c_void_p]),
+    "lcf_indice_conv_fwd_bf16x8": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int,
+                                           c_int, c_int, c_void_p, c_void_p, c_int, c_void_p,
+                                           c_void_p, c_int, _PI3, c_void_p]),
     "lcf_indice_conv_fwd_dense": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int,
                                           c_int, c_int, c_void_p, c_void_p, c_int, c_void_p,
                                           c_int, _PI3, c_void_p, c_void_p]),

@@ -564,7 +564,8 @@ static size_t tc_max(size_t a, size_t b) { return a > b ? a : b; }
 static size_t tc_lds_bytes(int CIN, int COUT, int TR, int kvol, bool bf16 = false, int nsets = 1,
                            int planes = 1)
 {
-    const int abufs = nsets == 1 ? 2 : 1; // one wave set double-buffers its rows, two do not
+    // one wave set double-buffers its rows; two sets, and the three-plane form, do not
+    const int abufs = (nsets == 1 && planes < 3) ? 2 : 1;
     size_t b = bf16 ? (size_t)nsets * abufs * planes * TR * (CIN + 8) * 2 // A rows, bf16
                     : (size_t)nsets * abufs * TR * (CIN + 4) * 4;         // A rows of one offset
     b += tc_max((size_t)nsets * (TR + 1) * (COUT + 4) * 4, (size_t)TR * kvol * 4); // tiles | nbr
@@ -585,6 +586,11 @@ static size_t tc_lds_bytes(int CIN, int COUT, int TR, int kvol, bool bf16 = fals
 // v_mfma_f32_16x16x32_bf16 (48 cycles) where fp32 operands need eight v_mfma_f32_16x16x4_f32
 // (256 cycles), and unlike those they overlap the loop's vector instructions.  Dropped terms are
 // <= 3 * 2^-18 of |a||w| per product (1.1e-5; fp32 products: 6e-8).
+// NP = 3: three planes, x = hi + mid + lo EXACTLY (8 + 8 + 8 significand bits; each residual is
+// exact in fp32), and the eight products down to 2^-24 |a||w| (hi*hi, hi*mid, mid*hi, hi*lo,
+// mid*mid, lo*hi, mid*lo, lo*mid; dropped: lo*lo, 2^-32): what is left is smaller than the
+// rounding of fp32 operands' own products, at 8 x 16 = 128 matrix-core cycles per 16x16x32 block
+// instead of 256 fp32-MFMA cycles.
 // NSETS = 2: a second set of waves takes every other step (offset), with its own row buffer and
 // its own output tile; the two tiles are summed (set 0 + set 1) in the epilogue.  Halves the
 // serial chain of a tile, which is what bounds layers with few tiles per CU.
@@ -602,7 +608,7 @@ cv_tc_kernel(const float *__restrict__ feat, const float *__restrict__ wimg,
     constexpr int WELEMS = C::WELEMS, MAXG = C::MAXG;
     constexpr bool AFULL = (ACH % THREADS) == 0;
     constexpr int DUMP = TR; // output-tile row that absorbs a group's padding entries
-    constexpr int ABUFS = NSETS == 1 ? 2 : 1;   // row buffers per wave set
+    constexpr int ABUFS = (NSETS == 1 && NP < 3) ? 2 : 1; // row buffers per wave set
     constexpr int TT = THREADS * NSETS;         // threads of the workgroup
     constexpr int NWT = C::NW * NSETS;          // waves of the workgroup
     constexpr int OTE = (TR + 1) * OSTR;        // floats of one output tile
@@ -750,11 +756,20 @@ cv_tc_kernel(const float *__restrict__ feat, const float *__restrict__ wimg,
                         const float4 v = a.v[g][x];
                         bf16x4 h = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
                         *reinterpret_cast<bf16x4 *>(dsth + (g * 16 + r) * ASTRH + cc * 4) = h;
-                        if constexpr (NP == 2) {
-                            bf16x4 l = {(__bf16)(v.x - (float)h[0]), (__bf16)(v.y - (float)h[1]),
-                                        (__bf16)(v.z - (float)h[2]), (__bf16)(v.w - (float)h[3])};
+                        if constexpr (NP >= 2) {
+                            const float4 r1 = make_float4(v.x - (float)h[0], v.y - (float)h[1],
+                                                          v.z - (float)h[2], v.w - (float)h[3]);
+                            bf16x4 l = {(__bf16)r1.x, (__bf16)r1.y, (__bf16)r1.z, (__bf16)r1.w};
                             *reinterpret_cast<bf16x4 *>(dsth + APL + (g * 16 + r) * ASTRH +
                                                         cc * 4) = l;
+                            if constexpr (NP == 3) {
+                                bf16x4 l2 = {(__bf16)(r1.x - (float)l[0]),
+                                             (__bf16)(r1.y - (float)l[1]),
+                                             (__bf16)(r1.z - (float)l[2]),
+                                             (__bf16)(r1.w - (float)l[3])};
+                                *reinterpret_cast<bf16x4 *>(dsth + 2 * APL + (g * 16 + r) * ASTRH +
+                                                            cc * 4) = l2;
+                            }
                         }
                     } else {
                         *reinterpret_cast<float4 *>(dst + (g * 16 + r) * ASTR + cc * 4) =
@@ -856,6 +871,14 @@ cv_tc_kernel(const float *__restrict__ feat, const float *__restrict__ wimg,
                             ah[ks * 2 + 1], w.h[t][ks * 2], acc[t], 0, 0, 0);
                         acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                             ah[ks * 2], w.h[t][ks * 2 + 1], acc[t], 0, 0, 0);
+                    }
+                    if constexpr (NP == 3) { // smallest terms first; (plane a, plane w)
+                        constexpr int TA[7] = {2, 1, 2, 1, 0, 1, 0};
+                        constexpr int TW[7] = {1, 2, 0, 1, 2, 0, 1};
+#pragma unroll
+                        for (int i = 0; i < 7; ++i)
+                            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                                ah[ks * 3 + TA[i]], w.h[t][ks * 3 + TW[i]], acc[t], 0, 0, 0);
                     }
                     acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[ks * NP], w.h[t][ks * NP],
                                                                      acc[t], 0, 0, 0);
@@ -1160,9 +1183,10 @@ extern "C" int lcf_indice_conv_fwd_bf16(const float *feat, const void *wimg_bf16
 // -------------------------------------------------------------------------- bf16x3 entry points
 __global__ void __launch_bounds__(256)
 cv_weight_image_bf16x3_kernel(const float *__restrict__ w, int kvol, int cin, int cout, int CIN,
-                              int COUT, int transpose, __bf16 *__restrict__ img)
+                              int COUT, int transpose, __bf16 *__restrict__ img, int planes)
 {
-    // two planes of the bf16 image (cv_weight_image_bf16_kernel): hi = bf16(w), lo = bf16(w - hi)
+    // two or three planes of the bf16 image (cv_weight_image_bf16_kernel): hi = bf16(w),
+    // mid = bf16(w - hi), lo = bf16(w - hi - mid)
     const int KS = CIN / 32;
     long long total = (long long)kvol * CIN * COUT;
     for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
@@ -1179,13 +1203,16 @@ cv_weight_image_bf16x3_kernel(const float *__restrict__ w, int kvol, int cin, in
             if (k < cout && c < cin) v = w[((size_t)o * cin + c) * cout + k];
         }
         const __bf16 h = (__bf16)v;
+        const float r1 = v - (float)h;
+        const __bf16 l = (__bf16)r1;
         img[e] = h;
-        img[total + e] = (__bf16)(v - (float)h);
+        img[total + e] = l;
+        if (planes == 3) img[2 * total + e] = (__bf16)(r1 - (float)l);
     }
 }
 
-extern "C" int lcf_weight_image_bf16x3(const float *w, int kvol, int cin, int cout, int transpose,
-                                       void *img, void *stream)
+static int cv_weight_image_split(const float *w, int kvol, int cin, int cout, int transpose,
+                                 void *img, void *stream, int planes)
 {
     if (!w || !img || kvol <= 0 || cin <= 0 || cout <= 0) return LCF_ERR_ARG;
     if (!cv_bf16_ok(cin) || !cv_bf16_ok(cout)) return LCF_ERR_UNSUPPORTED;
@@ -1194,35 +1221,47 @@ extern "C" int lcf_weight_image_bf16x3(const float *w, int kvol, int cin, int co
     int nb = (int)((total + 255) / 256);
     if (nb > 2048) nb = 2048;
     cv_weight_image_bf16x3_kernel<<<nb, 256, 0, (hipStream_t)stream>>>(
-        w, kvol, cin, cout, CIN, COUT, transpose, (__bf16 *)img);
+        w, kvol, cin, cout, CIN, COUT, transpose, (__bf16 *)img, planes);
     LCF_CHECK_LAUNCH();
     return LCF_OK;
 }
 
+extern "C" int lcf_weight_image_bf16x3(const float *w, int kvol, int cin, int cout, int transpose,
+                                       void *img, void *stream)
+{
+    return cv_weight_image_split(w, kvol, cin, cout, transpose, img, stream, 2);
+}
+
+extern "C" int lcf_weight_image_bf16x8(const float *w, int kvol, int cin, int cout, int transpose,
+                                       void *img, void *stream)
+{
+    return cv_weight_image_split(w, kvol, cin, cout, transpose, img, stream, 3);
+}
+
 // same launch-time choices as the fp32 form (cv_launch_tc): balanced tile height, second wave set
-template <int CIN, int COUT>
-static int cv_launch_tc_bf16x3(const float *feat, const float *wimg, const int *nbr, int k_cap,
-                               const int *k_dev, int kvol, int cin, int cout, const float *scale,
-                               const float *shift, int relu, float *out, hipStream_t st,
-                               TcDense dn)
+template <int CIN, int COUT, int NP>
+static int cv_launch_tc_split(const float *feat, const float *wimg, const int *nbr, int k_cap,
+                              const int *k_dev, int kvol, int cin, int cout, const float *scale,
+                              const float *shift, int relu, float *out, hipStream_t st,
+                              TcDense dn)
 {
     const int rows = g_rows_hint > 0 && g_rows_hint < k_cap ? g_rows_hint : k_cap;
     const int tr = tc_tile_rows(rows);
-    const bool two = g_tc_sets == 2 ||
-                     (g_tc_sets == 0 && tc_two_sets_fit(CIN, COUT, kvol, rows, tr, true, 2));
-    if (two && tc_lds_bytes(CIN, COUT, 32, kvol, true, 2, 2) <= 160 * 1024)
-        return cv_launch_tc_n<CIN, COUT, 32, true, 2, 2>(feat, wimg, nbr, k_cap, k_dev, kvol, cin,
-                                                         cout, scale, shift, relu, out, st, tr, dn);
-    return cv_launch_tc_n<CIN, COUT, 32, true, 1, 2>(feat, wimg, nbr, k_cap, k_dev, kvol, cin,
-                                                     cout, scale, shift, relu, out, st, tr, dn);
+    // three planes: a second wave set never paid (tools/bench_conv.py: 42 vs 50 us at 18.6k rows)
+    const bool two = g_tc_sets == 2 || (g_tc_sets == 0 && NP < 3 &&
+                                        tc_two_sets_fit(CIN, COUT, kvol, rows, tr, true, NP));
+    if (two && tc_lds_bytes(CIN, COUT, 32, kvol, true, 2, NP) <= 160 * 1024)
+        return cv_launch_tc_n<CIN, COUT, 32, true, 2, NP>(feat, wimg, nbr, k_cap, k_dev, kvol, cin,
+                                                          cout, scale, shift, relu, out, st, tr,
+                                                          dn);
+    return cv_launch_tc_n<CIN, COUT, 32, true, 1, NP>(feat, wimg, nbr, k_cap, k_dev, kvol, cin,
+                                                      cout, scale, shift, relu, out, st, tr, dn);
 }
 
-extern "C" int lcf_indice_conv_fwd_bf16x3(const float *feat, const void *wimg_bf16x3,
-                                          const int *nbr, int k_out, const int *k_out_dev,
-                                          int kvol, int cin, int cout, const float *scale,
-                                          const float *shift, int relu, float *out,
-                                          const int *dense_coors, int batch, const int shape[3],
-                                          void *stream)
+static int cv_fwd_split(const float *feat, const void *wimg_bf16x3, const int *nbr, int k_out,
+                        const int *k_out_dev, int kvol, int cin, int cout, const float *scale,
+                        const float *shift, int relu, float *out, const int *dense_coors,
+                        int batch, const int shape[3], void *stream, int planes)
 {
     if (k_out < 0 || kvol <= 0 || !wimg_bf16x3 || (k_out > 0 && (!feat || !out)) ||
         (!nbr && kvol != 1) || (dense_coors && (!shape || batch <= 0)))
@@ -1239,13 +1278,39 @@ extern "C" int lcf_indice_conv_fwd_bf16x3(const float *feat, const void *wimg_bf
     if (dense_coors) dn = TcDense{dense_coors, batch, shape[0], shape[1], shape[2]};
 #define CV_X3_CASE(A, B)                                                                      \
     if (cin == A && cout == B)                                                                \
-        return cv_launch_tc_bf16x3<A, B>(feat, wi, nbr, k_out, k_out_dev, kvol, cin, cout,    \
-                                         scale, shift, relu, out, st, dn);
+        return planes == 3 ? cv_launch_tc_split<A, B, 3>(feat, wi, nbr, k_out, k_out_dev, kvol, \
+                                                         cin, cout, scale, shift, relu, out,  \
+                                                         st, dn)                              \
+                           : cv_launch_tc_split<A, B, 2>(feat, wi, nbr, k_out, k_out_dev, kvol, \
+                                                         cin, cout, scale, shift, relu, out,  \
+                                                         st, dn);
     CV_X3_CASE(32, 32) CV_X3_CASE(32, 64) CV_X3_CASE(32, 128)
     CV_X3_CASE(64, 32) CV_X3_CASE(64, 64) CV_X3_CASE(64, 128)
     CV_X3_CASE(128, 32) CV_X3_CASE(128, 64) CV_X3_CASE(128, 128)
 #undef CV_X3_CASE
     return LCF_ERR_UNSUPPORTED;
+}
+
+extern "C" int lcf_indice_conv_fwd_bf16x3(const float *feat, const void *wimg_bf16x3,
+                                          const int *nbr, int k_out, const int *k_out_dev,
+                                          int kvol, int cin, int cout, const float *scale,
+                                          const float *shift, int relu, float *out,
+                                          const int *dense_coors, int batch, const int shape[3],
+                                          void *stream)
+{
+    return cv_fwd_split(feat, wimg_bf16x3, nbr, k_out, k_out_dev, kvol, cin, cout, scale, shift,
+                        relu, out, dense_coors, batch, shape, stream, 2);
+}
+
+extern "C" int lcf_indice_conv_fwd_bf16x8(const float *feat, const void *wimg_bf16x8,
+                                          const int *nbr, int k_out, const int *k_out_dev,
+                                          int kvol, int cin, int cout, const float *scale,
+                                          const float *shift, int relu, float *out,
+                                          const int *dense_coors, int batch, const int shape[3],
+                                          void *stream)
+{
+    return cv_fwd_split(feat, wimg_bf16x8, nbr, k_out, k_out_dev, kvol, cin, cout, scale, shift,
+                        relu, out, dense_coors, batch, shape, stream, 3);
 }
 
 // -------------------------------------------------------------------------- wgrad

@@ -49,9 +49,12 @@ class FrameEngine:
         calib: list of [N,F] float32 cuda clouds used to size the strided levels.
         conv_math: "f32" (fp32 MFMA, the default) or "bf16x3" (split operands on the bf16 matrix
         cores, lcf_indice_conv_fwd_bf16x3: ~1e-5 of the features' max magnitude instead of ~1e-7,
-        inside the 1e-4 feature tolerance; layers with 32/64/128 channels on both sides)."""
-        if conv_math not in ("f32", "bf16x3"):
-            raise ValueError("conv_math must be 'f32' or 'bf16x3'")
+        inside the 1e-4 feature tolerance; layers with 32/64/128 channels on both sides) or
+        "bf16x8" (three exact bf16 planes, eight products: fp32-grade results, ~1e-7, at half the
+        matrix-pipe cycles of the fp32 MFMA; the 64-channel layers only -- it does not pay on
+        the 32-channel ones)."""
+        if conv_math not in ("f32", "bf16x3", "bf16x8"):
+            raise ValueError("conv_math must be 'f32', 'bf16x3' or 'bf16x8'")
         self.conv_math = conv_math
         p = next(model.parameters(), None)
         self.dev = p.device if p is not None else torch.device("cuda", torch.cuda.current_device())
@@ -147,8 +150,12 @@ class FrameEngine:
         """Weight images and folded BatchNorm (eval) of every layer; VFE linear images."""
         with torch.no_grad():
             for l in self.layers:
-                l.x3 = self.conv_math == "bf16x3" and ops.bf16_supported(l.cin, l.cout)
-                l.wimg = (ops.weight_image_bf16x3 if l.x3 else ops.weight_image)(l.conv.weight)
+                l.x3 = (self.conv_math == "bf16x3" and ops.bf16_supported(l.cin, l.cout)) or (
+                    self.conv_math == "bf16x8" and l.cin >= 64 and
+                    ops.bf16_supported(l.cin, l.cout))
+                l.planes = 3 if self.conv_math == "bf16x8" else 2
+                l.wimg = ops.weight_image_bf16x3(l.conv.weight, planes=l.planes) if l.x3 \
+                    else ops.weight_image(l.conv.weight)
                 scale = shift = None
                 if l.bn is not None:
                     scale, shift = _bn_affine(l.bn)
@@ -383,7 +390,9 @@ class FrameEngine:
             if to_dense and self.two_streams:
                 main.wait_event(e_dense)
             if l.x3:
-                check(L.lcf_indice_conv_fwd_bf16x3(
+                fwd_split = L.lcf_indice_conv_fwd_bf16x8 if l.planes == 3 \
+                    else L.lcf_indice_conv_fwd_bf16x3
+                check(fwd_split(
                     P(feat), P(l.wimg), P(o.nbr), k_out_cap, P(k_out_dev), l.kvol, l.cin, l.cout,
                     P(l.scale), P(l.shift), int(l.relu), P(self.dense if to_dense else l.out),
                     P(coors) if to_dense else None, 1, i3(self.out_shape), st))

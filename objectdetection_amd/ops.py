@@ -232,12 +232,13 @@ class conv_math:
     """Context manager / setter for the MFMA operand type of indice_conv: "f32" (default, fp32
     MFMA); "bf16" for TRAINING (forward + dgrad through ``indice_conv`` with bf16 operands, fp32
     accumulate, tolerance 2e-2); "bf16x3" for INFERENCE (the no-grad forward of the sparse conv
-    modules with split hi + lo bf16 operands, fp32 tolerance; training under it stays fp32).
+    modules with split hi + lo bf16 operands, fp32 tolerance; "bf16x8": three exact planes and
+    eight products, fp32-grade; training under either stays fp32).
     Layers whose channels are not 32/64/128 stay fp32 in every mode."""
 
     def __init__(self, mode):
-        if mode not in ("f32", "bf16", "bf16x3"):
-            raise ValueError("conv math mode must be 'f32', 'bf16' or 'bf16x3'")
+        if mode not in ("f32", "bf16", "bf16x3", "bf16x8"):
+            raise ValueError("conv math mode must be 'f32', 'bf16', 'bf16x3' or 'bf16x8'")
         self.mode, self.prev = mode, None
 
     def __enter__(self):
@@ -287,21 +288,23 @@ def conv_forward_bf16(features, wimg, nbr, n_rows, kvol, cin, cout, scale=None, 
     return out
 
 
-def weight_image_bf16x3(weight, transpose=False):
-    """weight [...,Cin,Cout] -> two-plane (hi, lo) bf16 image for lcf_indice_conv_fwd_bf16x3."""
+def weight_image_bf16x3(weight, transpose=False, planes=2):
+    """weight [...,Cin,Cout] -> two-plane (hi, lo) bf16 image for lcf_indice_conv_fwd_bf16x3, or
+    (planes = 3) the three-plane image for lcf_indice_conv_fwd_bf16x8."""
     _need_cuda(weight)
     w = weight.detach().float().contiguous()
     cin, cout = int(w.shape[-2]), int(w.shape[-1])
     kvol = w.numel() // (cin * cout)
-    img = torch.empty((2 * kvol * cin * cout,), dtype=torch.int16, device=w.device)
-    check(_lib.lib().lcf_weight_image_bf16x3(_ptr(w), kvol, cin, cout, int(transpose), _ptr(img),
-                                             _stream()))
+    img = torch.empty((planes * kvol * cin * cout,), dtype=torch.int16, device=w.device)
+    L = _lib.lib()
+    fn = L.lcf_weight_image_bf16x8 if planes == 3 else L.lcf_weight_image_bf16x3
+    check(fn(_ptr(w), kvol, cin, cout, int(transpose), _ptr(img), _stream()))
     return img
 
 
 def conv_forward_bf16x3(features, wimg, nbr, n_rows, kvol, cin, cout, scale=None, shift=None,
                         relu=False, n_rows_dev=None, out=None, dense_coors=None, batch_size=1,
-                        shape=None):
+                        shape=None, planes=2):
     """conv_forward at fp32 tolerance on the bf16 matrix cores: operands split into hi + lo bf16
     planes, three products per term, fp32 accumulation (include/lcf.h).  With ``dense_coors`` the
     rows land in the dense [batch, cout, D, H, W] tensor (``out`` must then be cleared)."""
@@ -316,7 +319,9 @@ def conv_forward_bf16x3(features, wimg, nbr, n_rows, kvol, cin, cout, scale=None
         if out is None:
             out = torch.empty((n_rows, cout), dtype=torch.float32, device=x.device)
         dc, sh = None, None
-    check(_lib.lib().lcf_indice_conv_fwd_bf16x3(
+    L = _lib.lib()
+    fn = L.lcf_indice_conv_fwd_bf16x8 if planes == 3 else L.lcf_indice_conv_fwd_bf16x3
+    check(fn(
         _ptr(x), _ptr(wimg), _ptr(nbr), int(n_rows), _ptr(n_rows_dev), int(kvol), int(cin),
         int(cout), _ptr(scale), _ptr(shift), int(bool(relu)), _ptr(out), _ptr(dc),
         int(batch_size), sh, _stream()))

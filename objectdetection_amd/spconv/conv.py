@@ -138,21 +138,24 @@ class SparseConvolution(SparseModule):
         """No-grad forward: fp32 MFMA, or -- under ``ops.conv_math("bf16x3")`` and for 32 / 64 /
         128 channels on both sides -- split bf16 operands at fp32 tolerance (include/lcf.h)."""
         cin, cout = self.in_channels, self.out_channels
-        if ops.get_conv_math() == "bf16x3" and ops.bf16_supported(cin, cout):
-            return ops.conv_forward_bf16x3(x, self._weight_image(True), rb.out_nbr, rb.k_out,
-                                           rb.kvol, cin, cout, scale, shift, relu)
+        mode = ops.get_conv_math()
+        if mode in ("bf16x3", "bf16x8") and ops.bf16_supported(cin, cout):
+            planes = 3 if mode == "bf16x8" else 2
+            return ops.conv_forward_bf16x3(x, self._weight_image(planes), rb.out_nbr, rb.k_out,
+                                           rb.kvol, cin, cout, scale, shift, relu, planes=planes)
         return ops.conv_forward(x, self._weight_image(), rb.out_nbr, rb.k_out, rb.kvol, cin, cout,
                                 scale, shift, relu)
 
-    def _weight_image(self, split=False):
-        """MFMA weight image (split: the two-plane bf16x3 image), cached until the parameter is
-        modified in place or replaced."""
+    def _weight_image(self, planes=0):
+        """MFMA weight image (planes 2 / 3: the split bf16x3 / bf16x8 image), cached until the
+        parameter is modified in place or replaced."""
         w = self.weight
         tag = (w.data_ptr(), w._version, w.device, w.dtype)
-        name = "_wimg3" if split else "_wimg"
+        name = f"_wimg{planes}"
         cache = getattr(self, name, None)
         if cache is None or cache[0] != tag:
-            cache = (tag, (ops.weight_image_bf16x3 if split else ops.weight_image)(w))
+            img = ops.weight_image_bf16x3(w, planes=planes) if planes else ops.weight_image(w)
+            cache = (tag, img)
             object.__setattr__(self, name, cache)
         return cache[1]
 

@@ -415,6 +415,53 @@ def test_bf16x3_forward_matches_oracle_at_fp32_tolerance(oracle, cuda, cin, cout
         L.lcf_set_option(_lib.OPT_CONV_IMPL, 0)
 
 
+@pytest.mark.parametrize("cin,cout,subm,sets", [(64, 64, True, 1), (32, 64, False, 2),
+                                                (128, 128, True, 1), (64, 32, False, 1)])
+def test_bf16x8_forward_is_fp32_grade(oracle, cuda, cin, cout, subm, sets):
+    """Three-plane form (x = hi + mid + lo exactly, eight products): as close to the oracle as the
+    fp32 MFMA kernel is (both ~1e-7 of the output's max magnitude), on rows spread over 13
+    octaves; deterministic; the dense-target epilogue."""
+    from objectdetection_amd import _lib
+    rng = np.random.default_rng(cin * 9 + cout + sets)
+    coors = _frame_coors(oracle, 8, 6000)
+    extra = coors.copy()
+    extra[:, 3] = np.minimum(extra[:, 3] + 1, 1407)
+    coors = np.ascontiguousarray(np.unique(np.concatenate([coors, extra], 0), axis=0))
+    shape = [41, 1600, 1408]
+    k = coors.shape[0]
+    x = (rng.standard_normal((k, cin)) * np.exp2(rng.integers(-6, 7, (k, 1)))).astype(np.float32)
+    w = (rng.standard_normal((3, 3, 3, cin, cout)) / np.sqrt(27 * cin)).astype(np.float32)
+    if subm:
+        pairs, pn = oracle.rulebook_subm(coors, 1, shape, 3)
+        k_out = k
+    else:
+        oc, pairs, pn, _ = oracle.rulebook_conv(coors, 1, shape, 3, 2, 1)
+        k_out = oc.shape[0]
+    ref = oracle.indice_conv_fwd(x, w, pairs, pn, k_out)
+    rb = ops.build_rulebook(torch.from_numpy(coors).to(cuda), 1, shape, 3, 2, 1, 1, subm)
+    xt, wt = torch.from_numpy(x).to(cuda), torch.from_numpy(w).to(cuda)
+    img = ops.weight_image_bf16x3(wt, planes=3)
+    L = _lib.lib()
+    try:
+        assert L.lcf_set_option(_lib.OPT_CONV_SETS, sets) == 0
+        out = ops.conv_forward_bf16x3(xt, img, rb.out_nbr, rb.k_out, 27, cin, cout, planes=3)
+        again = ops.conv_forward_bf16x3(xt, img, rb.out_nbr, rb.k_out, 27, cin, cout, planes=3)
+        L.lcf_set_option(_lib.OPT_CONV_IMPL, 2)
+        f32 = ops.conv_forward(xt, ops.weight_image(wt), rb.out_nbr, rb.k_out, 27, cin, cout)
+        e8, e32 = rel_err(out.cpu().numpy(), ref), rel_err(f32.cpu().numpy(), ref)
+        assert e8 < 1e-6 and e8 < 3 * e32 + 1e-7, (e8, e32)
+        assert torch.equal(out, again)
+        if not subm:
+            sub = [int(rb.out_shape[0]), 64, 64]
+            d = ops.conv_forward_bf16x3(xt, img, rb.out_nbr, rb.k_out, 27, cin, cout,
+                                        dense_coors=rb.out_indices, batch_size=1, shape=sub,
+                                        planes=3)
+            assert torch.equal(d, ops.dense(out, rb.out_indices, 1, sub))
+    finally:
+        L.lcf_set_option(_lib.OPT_CONV_SETS, 0)
+        L.lcf_set_option(_lib.OPT_CONV_IMPL, 0)
+
+
 def test_bf16x3_identity_table_is_a_row_wise_linear_layer(cuda):
     """nbr = NULL, kvol = 1 (the row-wise linear form of the fp32 entry point) on split operands:
     against the float64 product, ragged row counts, device-side count below the capacity."""

@@ -173,3 +173,20 @@ def test_module_path_bf16x3_equals_engine_bf16x3(cuda):
     assert torch.equal(out, ref3)
     err = ((ref3 - ref32).abs().max() / ref32.abs().max()).item()
     assert 0 < err < 1e-4
+
+
+def test_engine_bf16x8_is_fp32_grade(cuda):
+    """conv_math="bf16x8": the 64-channel layers on three exact bf16 planes; the network's output
+    stays at fp32 reassociation distance from the fp32 module path."""
+    model = randomize_(SparseFrontEnd("M2").eval(), 0).to(cuda)
+    with torch.no_grad():
+        eng = model.engine(calib=_clouds(cuda, [0, 1], 20000), conv_math="bf16x8")
+        assert any(l.x3 and l.planes == 3 for l in eng.layers)
+        for seed, n in [(0, 20000), (7, 3000)]:
+            c = torch.from_numpy(synth.vkitti_frame(seed, n)).to(cuda)
+            out = eng.forward(c).clone()
+            eng.check()
+            ref = model([c])
+            err = ((out - ref).abs().max() / ref.abs().max()).item()
+            assert err < 2e-6
+            assert torch.equal(eng.forward(c), out)

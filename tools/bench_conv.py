@@ -40,17 +40,18 @@ def main():
             layers.append((f"{'subm' if conv.subm else 'conv'} {conv.in_channels}->"
                            f"{conv.out_channels} K={rb.k_out}", args, pairs))
             x = conv(x, _scale=scale, _shift=shift, _relu=True)
-    bf16_imgs, x3_imgs = {}, {}
+    bf16_imgs, x3_imgs, x8_imgs = {}, {}, {}
     mods_c = [m for m in mid.middle_conv if hasattr(m, "subm")]
     for li, conv in enumerate(mods_c):
         if ops.bf16_supported(conv.in_channels, conv.out_channels):
             bf16_imgs[li] = ops.weight_image_bf16(conv.weight)
             x3_imgs[li] = ops.weight_image_bf16x3(conv.weight)
+            x8_imgs[li] = ops.weight_image_bf16x3(conv.weight, planes=3)
     torch.cuda.synchronize()
     reps, rounds = 10, 5
     # slab; split-slab; tile-compacted: 1 set fixed 32-row tiles, 1 set, 2 sets (balanced tiles); bf16
     # x3_1 / x3_2: split-operand (bf16x3) form with one / two wave sets
-    splits = [1, "ss", "tc1_32", "tc1", "tc2", "bf16", "x3_1", "x3_2"]
+    splits = [1, "ss", "tc1_32", "tc1", "tc2", "bf16", "x3_1", "x3_2", "x8_1", "x8_2"]
     res = {}
     for r in range(rounds):
         for sp in splits:
@@ -58,8 +59,8 @@ def main():
             L.lcf_set_option(2, 32 if sp == "tc1_32" else 0)
             if sp == "bf16":
                 L.lcf_set_option(1, 0)
-            elif sp in ("x3_1", "x3_2"):
-                L.lcf_set_option(3, 1 if sp == "x3_1" else 2)
+            elif sp in ("x3_1", "x3_2", "x8_1", "x8_2"):
+                L.lcf_set_option(3, 1 if sp.endswith("_1") else 2)
             elif sp == "ss":
                 L.lcf_set_option(1, 3)
             elif sp == 1:
@@ -75,12 +76,16 @@ def main():
                         continue
                     fwd = ops.conv_forward_bf16
                     args = (args[0], bf16_imgs[li]) + args[2:]
-                if sp in ("x3_1", "x3_2"):
+                if sp in ("x3_1", "x3_2", "x8_1", "x8_2"):
                     if not ops.bf16_supported(args[5], args[6]):
                         res.setdefault((li, sp), []).append(float("nan"))
                         continue
-                    fwd = ops.conv_forward_bf16x3
-                    args = (args[0], x3_imgs[li]) + args[2:]
+                    if sp.startswith("x8"):
+                        fwd = lambda *a: ops.conv_forward_bf16x3(*a, planes=3)
+                        args = (args[0], x8_imgs[li]) + args[2:]
+                    else:
+                        fwd = ops.conv_forward_bf16x3
+                        args = (args[0], x3_imgs[li]) + args[2:]
                 fwd(*args)
                 e0 = torch.cuda.Event(enable_timing=True)
                 e1 = torch.cuda.Event(enable_timing=True)
@@ -105,12 +110,24 @@ def main():
             row += f"{us:9.1f}/{2.0 * pairs * cin * cout / us / 1e6:5.1f} "
         print(row)
     print("total us:", {sp: round(v, 1) for sp, v in tot.items()})
-    # error of the split-operand form against the fp32 kernel, relative to the max magnitude
+    # errors against a float64 reference (per-offset gather + matmul in double), relative to the
+    # output's max magnitude: fp32 MFMA kernel, bf16x3, bf16x8
+    mods_w = [m.weight for m in mods_c]
     for li, (name, args, pairs) in enumerate(layers):
-        if li in x3_imgs:
-            a = ops.conv_forward(*args)
-            b = ops.conv_forward_bf16x3(args[0], x3_imgs[li], *args[2:])
-            print(f"x3 vs fp32 {name:30s} {float((a - b).abs().max() / a.abs().max()):.2e}")
+        if li not in x3_imgs:
+            continue
+        x, _, nbr, k_out, kvol, cin, cout, scale, shift, relu = args
+        w = mods_w[li].detach().double().reshape(kvol, cin, cout)
+        ref = torch.zeros((k_out, cout), dtype=torch.float64, device=x.device)
+        for o in range(kvol):
+            idx = nbr[:, o].long()
+            v = idx >= 0
+            ref[v] += x[idx[v]].double() @ w[o]
+        ref = torch.relu(ref * scale.double() + shift.double())
+        e = lambda t: float((t.double() - ref).abs().max() / ref.abs().max())
+        print(f"err vs f64 {name:30s} fp32 {e(ops.conv_forward(*args)):.2e}  "
+              f"x3 {e(ops.conv_forward_bf16x3(x, x3_imgs[li], *args[2:])):.2e}  "
+              f"x8 {e(ops.conv_forward_bf16x3(x, x8_imgs[li], *args[2:], planes=3)):.2e}")
 
 
 if __name__ == "__main__":
