@@ -245,6 +245,14 @@ int lcf_indice_conv_wgrad_bf16(const float *feat, const float *dout, const int *
                                int kvol, int cin, int cout, int planes, float *dw,
                                void *stream);
 
+/* Frame hand-over for a caller that keeps a static point buffer and a device-side point count
+ * (FrameEngine; no counterpart in the reference): dst[0 : n*f] = points[0 : n*f] and
+ * n_dev[0] = n_total (>= n: dst may point behind points already in the buffer, the light-curtain
+ * loop's append), one launch.  n * f must be a multiple of 4 and both pointers 16-byte aligned
+ * (LCF_ERR_UNSUPPORTED otherwise: copy and fill separately). */
+int lcf_load_points(const float *points, int n, int f, float *dst, int n_total, int *n_dev,
+                    void *stream);
+
 /* Fill `bytes` (multiple of 4, 4-byte aligned) with a 32-bit pattern: a plain kernel, usable
  * where hipMemsetAsync is not wanted (graph capture; no counterpart in the reference). */
 int lcf_fill_u32(void *p, uint32_t value, size_t bytes, void *stream);

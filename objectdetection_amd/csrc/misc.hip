@@ -53,6 +53,35 @@ extern "C" int lcf_fill_u32(void *p, uint32_t value, size_t bytes, void *stream)
     return lcf_fill32(p, value, bytes, (hipStream_t)stream);
 }
 
+// ---------------------------------------------------------------- frame hand-over
+// One launch in front of a captured frame: the new points into the engine's static point buffer
+// (dst = where they go: the buffer's start, or behind the cloud already there) and the total
+// point count into the device-side counter (instead of a copy and a fill).
+__global__ void __launch_bounds__(256)
+load_points_kernel(const float4 *__restrict__ src, float4 *__restrict__ dst, long long n4,
+                   int n_total, int *__restrict__ n_dev)
+{
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t == 0) n_dev[0] = n_total;
+    if (t < n4) dst[t] = src[t];
+}
+
+extern "C" int lcf_load_points(const float *points, int n, int f, float *dst, int n_total,
+                               int *n_dev, void *stream)
+{
+    if (n < 0 || f <= 0 || n_total < n || !dst || !n_dev || (n > 0 && !points))
+        return LCF_ERR_ARG;
+    const long long elems = (long long)n * f;
+    if ((elems & 3) || ((uintptr_t)points & 15) || ((uintptr_t)dst & 15))
+        return LCF_ERR_UNSUPPORTED; // float4 copies: n * f a multiple of 4, 16-byte aligned
+    const long long n4 = elems / 4;
+    const unsigned nb = (unsigned)((n4 + 255) / 256);
+    load_points_kernel<<<nb ? nb : 1, 256, 0, (hipStream_t)stream>>>(
+        (const float4 *)points, (float4 *)dst, n4, n_total, n_dev);
+    LCF_CHECK_LAUNCH();
+    return LCF_OK;
+}
+
 // ---------------------------------------------------------------- dense
 // SparseConvTensor.dense() (second/pytorch/models/middle.py:206): [B,C,D,H,W] contiguous.
 // Thread = (row, channel); a row's C values land C*svol*4 bytes apart, so writes are scattered by

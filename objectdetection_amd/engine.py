@@ -434,9 +434,22 @@ class FrameEngine:
             raise RuntimeError(f"FrameEngine: {n} points exceed max_points={self.max_points}")
         if points.shape[1] != self.F or points.dtype != torch.float32 or not points.is_cuda:
             raise ValueError("points must be a [N,4] float32 cuda tensor")
-        self.points[:n].copy_(points, non_blocking=True)
-        self.n_dev.fill_(n)
+        self._copy_in(points, 0, n, n)
         self.n_points = n
+
+    def _copy_in(self, src, row0, rows, total):
+        """points[row0 : row0 + rows] = src and n_dev = total, as one launch where the float4 copy
+        applies (F = 4 rows are 16 bytes), else a copy and a fill."""
+        if rows > 0 and src.is_contiguous() and src.data_ptr() % 16 == 0:
+            rc = self.L.lcf_load_points(src.data_ptr(), rows, self.F,
+                                        self.points[row0:].data_ptr(), total,
+                                        self.n_dev.data_ptr(),
+                                        torch.cuda.current_stream(self.dev).cuda_stream)
+            if rc == 0:
+                return
+        if rows > 0:
+            self.points[row0:row0 + rows].copy_(src, non_blocking=True)
+        self.n_dev.fill_(total)
 
     def forward_append(self, new_points, sync=False):
         """The light-curtain loop (second/light_curtain/utils.py:121-124 stacks every curtain's
@@ -450,9 +463,8 @@ class FrameEngine:
         if new_points.shape[1] != self.F or new_points.dtype != torch.float32 \
                 or not new_points.is_cuda:
             raise ValueError("points must be a [M,4] float32 cuda tensor")
-        self.points[n0:n0 + m].copy_(new_points, non_blocking=True)
         self.n_points = n0 + m
-        self.n_dev.fill_(self.n_points)
+        self._copy_in(new_points, n0, m, self.n_points)
         return self._run(self.points[:self.n_points], sync)
 
     def forward(self, points, sync=False):

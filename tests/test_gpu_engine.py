@@ -190,3 +190,26 @@ def test_engine_bf16x8_is_fp32_grade(cuda):
             err = ((out - ref).abs().max() / ref.abs().max()).item()
             assert err < 2e-6
             assert torch.equal(eng.forward(c), out)
+
+
+def test_load_points_copies_and_counts_in_one_launch(cuda):
+    """lcf_load_points: the rows land where dst points, the device-side counter gets n_total;
+    what the float4 copy cannot do is refused (the engine then copies and fills separately)."""
+    L = _lib.lib()
+    src = torch.randn((1000, 4), device=cuda)
+    buf = torch.zeros((3000, 4), device=cuda)
+    n_dev = torch.zeros((1,), dtype=torch.int32, device=cuda)
+    st = torch.cuda.current_stream().cuda_stream
+    assert L.lcf_load_points(src.data_ptr(), 1000, 4, buf[500:].data_ptr(), 1500,
+                             n_dev.data_ptr(), st) == 0
+    assert torch.equal(buf[500:1500], src) and int(n_dev) == 1500
+    assert float(buf[:500].abs().sum()) == 0 and float(buf[1500:].abs().sum()) == 0
+    assert L.lcf_load_points(src.data_ptr(), 0, 4, buf.data_ptr(), 7, n_dev.data_ptr(), st) == 0
+    assert int(n_dev) == 7
+    assert L.lcf_load_points(src.data_ptr(), 1000, 4, buf.data_ptr(), 999, n_dev.data_ptr(),
+                             st) == -1  # n_total < n
+    assert L.lcf_load_points(src.data_ptr(), 5, 3, buf.data_ptr(), 5, n_dev.data_ptr(),
+                             st) == -3  # 15 floats: not a whole number of float4
+    assert L.lcf_load_points(src.data_ptr() + 4, 4, 4, buf.data_ptr(), 4, n_dev.data_ptr(),
+                             st) == -3  # misaligned source
+    torch.cuda.synchronize()
