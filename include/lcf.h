@@ -245,6 +245,14 @@ int lcf_indice_conv_wgrad_bf16(const float *feat, const float *dout, const int *
                                int kvol, int cin, int cout, int planes, float *dw,
                                void *stream);
 
+/* Batched fills (no counterpart in the reference; process-wide state like lcf_set_option, not
+ * thread-safe): between lcf_fill_batch_begin() and lcf_fill_batch_flush(stream) the fills that
+ * lcf_fill_u32 and the lcf_*_workspace_reset calls would launch are recorded (their stream
+ * argument is ignored) and the flush runs all of them as ONE kernel on `stream`.  Any other entry
+ * point must not be called in between. */
+int lcf_fill_batch_begin(void);
+int lcf_fill_batch_flush(void *stream);
+
 /* Frame hand-over for a caller that keeps a static point buffer and a device-side point count
  * (FrameEngine; no counterpart in the reference): dst[0 : n*f] = points[0 : n*f] and
  * n_dev[0] = n_total (>= n: dst may point behind points already in the buffer, the light-curtain

@@ -71,6 +71,8 @@ SYMBOLS = {
     "lcf_linear_wgrad": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "lcf_indice_conv_wgrad_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                            c_int, c_int, c_void_p, c_void_p]),
+    "lcf_fill_batch_begin": (c_int, []),
+    "lcf_fill_batch_flush": (c_int, [c_void_p]),
     "lcf_load_points": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     "lcf_dense": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, _PI3, c_int,
                           c_void_p, c_void_p]),

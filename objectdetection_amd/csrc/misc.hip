@@ -34,11 +34,93 @@ __global__ void __launch_bounds__(256) lcf_fill32_kernel(uint32_t *p, uint32_t v
 
 int g_lcf_ws_clean = 0;
 
+// Batched fills: between lcf_fill_batch_begin() and lcf_fill_batch_flush() every fill the library
+// would launch (workspace resets, lcf_fill_u32) is recorded instead, and the flush runs them as
+// ONE kernel -- the engine re-arms ten hash workspaces and clears the dense output behind a
+// frame's rulebook branch: eleven 4-5 us launches there become one.
+#define FILL_MAX_SEGS 16
+struct FillSeg {
+    uint32_t *p;
+    uint32_t v;
+    unsigned blk0; // first workgroup of the segment
+    unsigned long long n32;
+};
+struct FillPlan {
+    FillSeg s[FILL_MAX_SEGS];
+    int n;
+};
+static FillPlan g_fill_plan;
+static int g_fill_batching = 0;
+static unsigned g_fill_blocks = 0;
+
+__global__ void __launch_bounds__(256) lcf_fill32_multi_kernel(FillPlan plan)
+{
+    int i = 0;
+#pragma unroll 1
+    for (int j = 1; j < plan.n; ++j)
+        if (blockIdx.x >= plan.s[j].blk0) i = j;
+    const FillSeg sg = plan.s[i];
+    const unsigned nblk = (i + 1 < plan.n ? plan.s[i + 1].blk0 : gridDim.x) - sg.blk0;
+    uint32_t *p = sg.p;
+    const size_t n32 = sg.n32;
+    size_t head = ((16 - ((uintptr_t)p & 15)) & 15) / 4;
+    if (head > n32) head = n32;
+    const size_t body = (n32 - head) / 4;
+    uint4 *p4 = reinterpret_cast<uint4 *>(p + head);
+    const uint4 v4 = make_uint4(sg.v, sg.v, sg.v, sg.v);
+    const size_t stride = (size_t)nblk * 256;
+    const size_t t = (size_t)(blockIdx.x - sg.blk0) * 256 + threadIdx.x;
+    for (size_t e = t; e < body; e += stride) p4[e] = v4;
+    if (t < head) p[t] = sg.v;
+    const size_t tail0 = head + body * 4;
+    if (t < n32 - tail0) p[tail0 + t] = sg.v;
+}
+
+static int fill_plan_launch(hipStream_t st)
+{
+    if (g_fill_plan.n == 0) return LCF_OK;
+    lcf_fill32_multi_kernel<<<g_fill_blocks, 256, 0, st>>>(g_fill_plan);
+    g_fill_plan.n = 0;
+    g_fill_blocks = 0;
+    LCF_CHECK_LAUNCH();
+    return LCF_OK;
+}
+
+extern "C" int lcf_fill_batch_begin(void)
+{
+    g_fill_plan.n = 0;
+    g_fill_blocks = 0;
+    g_fill_batching = 1;
+    return LCF_OK;
+}
+
+extern "C" int lcf_fill_batch_flush(void *stream)
+{
+    g_fill_batching = 0;
+    return fill_plan_launch((hipStream_t)stream);
+}
+
 int lcf_fill32(void *p, uint32_t v, size_t bytes, hipStream_t st)
 {
     if (bytes == 0) return LCF_OK;
     if ((bytes & 3) || ((uintptr_t)p & 3)) return LCF_ERR_ARG;
     size_t n32 = bytes / 4;
+    if (g_fill_batching) {
+        if (g_fill_plan.n == FILL_MAX_SEGS) { // full: run what is recorded so far
+            int rc = fill_plan_launch(st);
+            if (rc != LCF_OK) return rc;
+        }
+        size_t nbs = (n32 / 4 + 255) / 256;
+        if (nbs < 1) nbs = 1;
+        if (nbs > 2048) nbs = 2048;
+        FillSeg &sg = g_fill_plan.s[g_fill_plan.n++];
+        sg.p = (uint32_t *)p;
+        sg.v = v;
+        sg.blk0 = g_fill_blocks;
+        sg.n32 = n32;
+        g_fill_blocks += (unsigned)nbs;
+        return LCF_OK;
+    }
     size_t nb = (n32 / 4 + 255) / 256;
     if (nb < 1) nb = 1;
     if (nb > 4096) nb = 4096;

@@ -338,14 +338,25 @@ class FrameEngine:
                     e = torch.cuda.Event()
                     e.record(side)
                     ready[id(o)] = e
-            check(L.lcf_fill_u32(P(self.dense), 0, self.dense.numel() * 4, sst))
-            if self.two_streams:
-                e_dense = torch.cuda.Event()
-                e_dense.record(side)
-            self._reset_workspaces(sst)  # for the next frame
+            # the dense clear and the re-arming of the ten hash workspaces (for the next frame)
+            # as ONE fill launch at the end of the branch
+            batch = os.environ.get("LCF_ENGINE_FILL_BATCH", "1") != "0"
+            if batch:
+                check(L.lcf_fill_batch_begin())
+            try:
+                check(L.lcf_fill_u32(P(self.dense), 0, self.dense.numel() * 4, sst))
+                if self.two_streams and not batch:
+                    e_dense = torch.cuda.Event()
+                    e_dense.record(side)
+                self._reset_workspaces(sst)
+            finally:
+                if batch:
+                    check(L.lcf_fill_batch_flush(sst))
             if self.two_streams:
                 e_side = torch.cuda.Event()
                 e_side.record(side)
+                if batch:
+                    e_dense = e_side
         # ---- main stream: features
         if self.vfe_kind == "vfe" and self.vfe_fused:
             (w1, c0, u1, s1, h1), (w2, _, u2, s2, h2), (w3, _, u3, s3, h3) = self.lin

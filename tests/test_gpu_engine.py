@@ -213,3 +213,28 @@ def test_load_points_copies_and_counts_in_one_launch(cuda):
     assert L.lcf_load_points(src.data_ptr() + 4, 4, 4, buf.data_ptr(), 4, n_dev.data_ptr(),
                              st) == -3  # misaligned source
     torch.cuda.synchronize()
+
+
+def test_batched_fills_run_as_one_launch_with_the_same_result(cuda):
+    """lcf_fill_batch_begin / _flush: recorded fills (ragged sizes, unaligned heads, more segments
+    than one plan holds) land exactly as separate lcf_fill_u32 calls would."""
+    L = _lib.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    sizes = [1, 3, 4, 5, 255, 256, 1000, 4097, 70001, 12, 7, 33, 64, 129, 100000, 2, 9, 31, 513]
+    bufs = [torch.full((n + 3,), 5, dtype=torch.int32, device=cuda) for n in sizes]
+    assert L.lcf_fill_batch_begin() == 0
+    for i, (b, n) in enumerate(zip(bufs, sizes)):
+        off = i % 3  # unaligned starts
+        assert L.lcf_fill_u32(b[off:].data_ptr(), 1000 + i, n * 4, st) == 0
+    torch.cuda.synchronize()
+    assert all(int((b != 5).sum()) == 0 for b in bufs[-3:])  # recorded, not yet run
+    assert L.lcf_fill_batch_flush(st) == 0
+    for i, (b, n) in enumerate(zip(bufs, sizes)):
+        off = i % 3
+        ref = torch.full_like(b, 5)
+        ref[off:off + n] = 1000 + i
+        assert torch.equal(b, ref), i
+    # outside a batch fills run immediately again
+    assert L.lcf_fill_u32(bufs[0].data_ptr(), 1, 4, st) == 0
+    torch.cuda.synchronize()
+    assert int(bufs[0][0]) == 1
