@@ -67,6 +67,9 @@ int lcf_version(void);
  * (lcf_*_workspace_reset below, e.g. enqueued behind the previous frame, off its critical path);
  * the calls leave it dirty.  0 (default) = every call resets its workspace itself. */
 #define LCF_OPT_WS_CLEAN 5
+/* LCF_OPT_NBR_CLEAN: 1 = lcf_rulebook_conv_fill skips filling out_nbr / in_nbr with -1: the
+ * caller has done it (e.g. all tables of a frame in one lcf_fill_batch launch).  Default 0. */
+#define LCF_OPT_NBR_CLEAN 6
 int lcf_set_option(int option, int value);
 
 /* ------------------------------------------------------------------------------------------

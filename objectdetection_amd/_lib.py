@@ -112,6 +112,7 @@ SYMBOLS = {
 # lcf_set_option keys (include/lcf.h)
 OPT_CONV_SPLIT, OPT_CONV_IMPL, OPT_CONV_TILE, OPT_CONV_SETS, OPT_CONV_ROWS_HINT = 0, 1, 2, 3, 4
 OPT_WS_CLEAN = 5
+OPT_NBR_CLEAN = 6
 
 _lib = None
 

@@ -20,6 +20,8 @@ __global__ void lcf_fill32_kernel(uint32_t *p, uint32_t v, size_t n32);
 int lcf_fill32(void *p, uint32_t v, size_t bytes, hipStream_t st);
 // LCF_OPT_WS_CLEAN: the caller hands in workspaces already in their reset state (misc.hip)
 extern int g_lcf_ws_clean;
+// LCF_OPT_NBR_CLEAN: lcf_rulebook_conv_fill's neighbour tables arrive filled with -1 (misc.hip)
+extern int g_lcf_nbr_clean;
 
 static inline size_t lcf_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 

@@ -1682,6 +1682,11 @@ extern "C" int lcf_set_option(int option, int value)
         g_lcf_ws_clean = value;
         return LCF_OK;
     }
+    if (option == LCF_OPT_NBR_CLEAN) {
+        if (value != 0 && value != 1) return LCF_ERR_ARG;
+        g_lcf_nbr_clean = value;
+        return LCF_OK;
+    }
     if (option == LCF_OPT_CONV_ROWS_HINT) {
         if (value < 0) return LCF_ERR_ARG;
         g_rows_hint = value;

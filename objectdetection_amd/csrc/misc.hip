@@ -33,6 +33,7 @@ __global__ void __launch_bounds__(256) lcf_fill32_kernel(uint32_t *p, uint32_t v
 }
 
 int g_lcf_ws_clean = 0;
+int g_lcf_nbr_clean = 0;
 
 // Batched fills: between lcf_fill_batch_begin() and lcf_fill_batch_flush() every fill the library
 // would launch (workspace resets, lcf_fill_u32) is recorded instead, and the flush runs them as

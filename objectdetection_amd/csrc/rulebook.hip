@@ -537,12 +537,14 @@ extern "C" int lcf_rulebook_conv_fill(const int *coors, int k_in, const int *k_i
     ConvWs w = rb_conv_carve(ws, k_in, g.E);
     if (ws_bytes < w.bytes) return LCF_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
-    if (k_out > 0 &&
-        lcf_fill32(out_nbr, 0xFFFFFFFFu, (size_t)k_out * g.kvol * 4, st) != LCF_OK)
-        return LCF_ERR_LAUNCH;
-    if (k_in > 0 && in_nbr &&
-        lcf_fill32(in_nbr, 0xFFFFFFFFu, (size_t)k_in * g.kvol * 4, st) != LCF_OK)
-        return LCF_ERR_LAUNCH;
+    if (!g_lcf_nbr_clean) { // LCF_OPT_NBR_CLEAN: the caller has filled both tables with -1
+        if (k_out > 0 &&
+            lcf_fill32(out_nbr, 0xFFFFFFFFu, (size_t)k_out * g.kvol * 4, st) != LCF_OK)
+            return LCF_ERR_LAUNCH;
+        if (k_in > 0 && in_nbr &&
+            lcf_fill32(in_nbr, 0xFFFFFFFFu, (size_t)k_in * g.kvol * 4, st) != LCF_OK)
+            return LCF_ERR_LAUNCH;
+    }
     if (k_in == 0 || k_out == 0) return LCF_OK;
     unsigned nb = (unsigned)((w.total + RB_BLOCK - 1) / RB_BLOCK);
     rb_conv_fill_kernel<<<nb, RB_BLOCK, 0, st>>>(coors, k_in, k_in_dev, batch, g, k_out, k_out_dev,

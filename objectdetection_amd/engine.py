@@ -283,10 +283,13 @@ class FrameEngine:
         the graph: two branches that join at each conv."""
         L = self.L
         L.lcf_set_option(_lib.OPT_WS_CLEAN, int(os.environ.get("LCF_ENGINE_WS_CLEAN", "1")))
+        self.nbr_clean = os.environ.get("LCF_ENGINE_NBR_CLEAN", "1") != "0"
+        L.lcf_set_option(_lib.OPT_NBR_CLEAN, int(self.nbr_clean))
         try:
             self._enqueue_clean()
         finally:
             L.lcf_set_option(_lib.OPT_WS_CLEAN, 0)
+            L.lcf_set_option(_lib.OPT_NBR_CLEAN, 0)
             L.lcf_set_option(_lib.OPT_CONV_ROWS_HINT, 0)
 
     def _enqueue_clean(self):
@@ -298,10 +301,20 @@ class FrameEngine:
         MV, T, F = self.max_voxels, self.T, self.F
         if self.two_streams:  # overflow flags: only the rulebook branch writes them
             side.wait_stream(main)
+        if self.nbr_clean:
+            # the overflow flags and the strided levels' neighbour tables (-1 = no pair) in one
+            # fill launch at the head of the rulebook branch (the previous frame is complete)
+            check(L.lcf_fill_batch_begin())
+            try:
+                check(L.lcf_fill_u32(P(self.flags), 0, self.flags.numel() * 4, sst))
+                for l in self.layers:
+                    if not l.subm:
+                        check(L.lcf_fill_u32(P(l.nbr), 0xFFFFFFFF, l.nbr.numel() * 4, sst))
+            finally:
+                check(L.lcf_fill_batch_flush(sst))
+        else:
             with torch.cuda.stream(side):
                 self.flags.zero_()
-        else:
-            self.flags.zero_()
         check(L.lcf_voxelize(P(self.points), self.max_points, P(self.n_dev), F, f3(self.vs),
                              f6(self.rng), T, MV, self.cap_mode, 0, 4, P(self.voxels),
                              P(self.coors), P(self.num), P(self.vnum), P(self.vox_ws),

@@ -553,6 +553,8 @@ def test_option_values_are_validated(cuda):
     assert L.lcf_set_option(_lib.OPT_CONV_SETS, 3) != 0
     assert L.lcf_set_option(_lib.OPT_CONV_IMPL, 4) != 0
     assert L.lcf_set_option(_lib.OPT_WS_CLEAN, 2) != 0
+    assert L.lcf_set_option(_lib.OPT_NBR_CLEAN, 2) != 0
+    assert L.lcf_set_option(_lib.OPT_NBR_CLEAN, 0) == 0
     assert L.lcf_set_option(99, 0) != 0
 
 
