@@ -107,7 +107,7 @@ def train_measurement(args, dev, rank, world, dist, barrier):
     frames = [torch.from_numpy(synth.vkitti_frame(1000 + rank * 2 * b + i, args.points)).to(dev)
               for i in range(2 * b)]
     batches = [frames[:b], frames[b:]]
-    for i in range(3):
+    for i in range(6):  # MIOpen times its solvers for the RPN on the first steps
         step(batches[i % 2])
     barrier()
     t0 = time.perf_counter()
@@ -145,7 +145,7 @@ def main():
     ap.add_argument("--max-voxels", type=int, default=40000)
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--train-steps", type=int, default=10,
+    ap.add_argument("--train-steps", type=int, default=30,
                     help="timed training steps of the second measurement (0 = skip it)")
     ap.add_argument("--train-batch", type=int, default=8, help="frames per rank per step")
     ap.add_argument("--inflight", type=int, default=1,

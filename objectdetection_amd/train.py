@@ -61,7 +61,7 @@ class TrainStep:
     """Owns the model, the flat gradient bucket and the optimizer of ONE rank."""
 
     def __init__(self, device, model="M2", lr=3e-4, seed=0, process_group=None,
-                 conv_math="bf16"):
+                 conv_math="bf16", freeze_gc_after=5):
         # conv_math "bf16": indice_conv forward + dgrad with bf16 MFMA operands and fp32
         # accumulation (BASELINE.json configs[2]); fp32 master weights, fp32 wgrad.
         self.device = device
@@ -77,10 +77,22 @@ class TrainStep:
         self.opt = torch.optim.AdamW(self.net.parameters(), lr=lr, weight_decay=0.01,
                                      fused=torch.device(device).type == "cuda")
         self.gen = torch.Generator(device=device).manual_seed(seed)
+        # Python's cyclic collector: a full (generation-2) pass over the model's, optimizer's and
+        # autograd's long-lived objects stalls the host for ~80 ms every 30-100 steps (a 17.6 ms
+        # step averages 20 ms over 30 steps).  Once the step has reached its steady state
+        # everything alive is moved to the permanent generation (gc.freeze(); the collector stays
+        # enabled): 160 steps measured without one pause.  None disables.
+        self.freeze_gc_after = freeze_gc_after
+        self.calls = 0
 
     def __call__(self, clouds):
         """clouds: this rank's scenes (list of [N,4] cuda tensors) -> loss (device scalar)."""
         from . import ops
+        self.calls += 1
+        if self.freeze_gc_after is not None and self.calls == self.freeze_gc_after + 1:
+            import gc
+            gc.collect()
+            gc.freeze()
         self.bucket.zero()
         with ops.conv_math(self.conv_math):
             loss = synthetic_loss(self.net(clouds), self.gen)
