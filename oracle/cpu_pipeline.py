@@ -1,8 +1,9 @@
 """CPU baseline of the whole hot path -- TEST / BENCH INFRASTRUCTURE ONLY (see oracle/__init__.py).
 
 Reference-faithful restatement of what the reference runs on a CPU (BASELINE.md "CPU-baseline
-plan"): sequential dense-table voxelizer (numba points_to_voxel twin, 1 thread), the reference's
-own VFE torch ops on CPU tensors, dense-grid sequential get_indice_pairs, and spconv's CPU
+plan"): sequential dense-table voxelizer (numba points_to_voxel twin, 1 thread), the VFE of
+oracle/vfe_oracle.py (numpy; pinned by reference-generated goldens -- never the product's
+voxel_encoder module), dense-grid sequential get_indice_pairs, and spconv's CPU
 indice_conv = per kernel offset gather -> torch.mm -> scatter-add (torch threads), then dense().
 A restatement ("port"), not the original numba/spconv binaries, which are absent.
 """
@@ -12,6 +13,7 @@ import numpy as np
 import torch
 
 import oracle
+from oracle import vfe_oracle
 
 
 def indice_conv_mm(feats, weight, pairs, pair_num, k_out):
@@ -26,6 +28,21 @@ def indice_conv_mm(feats, weight, pairs, pair_num, k_out):
         j = torch.from_numpy(pairs[1, o, :n].astype(np.int64))
         out.index_add_(0, j, feats.index_select(0, i) @ w[o])
     return out
+
+
+def run_vfe(vfe, voxels, num):
+    """The VFE stage on oracle/vfe_oracle.py.  `vfe` is only a parameter holder (state_dict keys
+    are the reference's) and names the variant; eval-mode BatchNorm."""
+    params = {k: v.detach().cpu().numpy() for k, v in vfe.state_dict().items()}
+    kind = type(vfe).__name__
+    if kind == "SimpleVoxel":
+        return vfe_oracle.simple_voxel(voxels, num, voxels.shape[2])
+    if kind == "SimpleVoxelRadius":
+        return vfe_oracle.simple_voxel_radius(voxels, num, voxels.shape[2])
+    if kind == "VoxelFeatureExtractor":
+        return vfe_oracle.voxel_feature_extractor(
+            voxels, num, params, with_distance=bool(getattr(vfe, "_with_distance", False)))
+    raise NotImplementedError(f"cpu_pipeline: no oracle for VFE {kind}")
 
 
 def run_middle(seq, feats, coors, shape, batch):
@@ -65,10 +82,9 @@ def frontend_forward(model_cpu, clouds):
         vs.append(v)
         ns.append(n)
         cs.append(np.concatenate([np.full((c.shape[0], 1), b, np.int32), c], 1))
-    voxels = torch.from_numpy(np.concatenate(vs))
-    num = torch.from_numpy(np.concatenate(ns))
     coors = np.ascontiguousarray(np.concatenate(cs))
-    feats = model_cpu.voxel_feature_extractor(voxels, num, torch.from_numpy(coors))
+    feats = run_vfe(model_cpu.voxel_feature_extractor, np.concatenate(vs), np.concatenate(ns))
+    feats = torch.from_numpy(np.ascontiguousarray(feats, dtype=np.float32))
     mid = model_cpu.middle_feature_extractor
     shape = [int(s) for s in mid.sparse_shape]
     feats, coors, shape = run_middle(mid.middle_conv, feats, coors, shape, len(clouds))
