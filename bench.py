@@ -13,6 +13,8 @@ collective; SURVEY.md section 8e: "inference: replicas only") and reports the wh
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -131,7 +133,26 @@ def train_measurement(args, dev, rank, world, dist, barrier):
             "loss": round(float(loss), 4)}
 
 
-def main():
+def launch_ranks(n, argv, script=None):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script as CHILD
+    processes (one per GPU, torch.distributed.run, rendezvous on 127.0.0.1) and return their exit
+    code; rank 0's JSON line reaches stdout through the inherited descriptor.  Called before this
+    process has made any GPU call -- a process that has initialised the GPU must never be
+    replaced or re-executed on this pool, and this one only relays.  (The reference's multi-GPU
+    switch is second/pytorch/train.py:204-205, single-process DataParallel.)"""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+           f"--nproc-per-node={int(n)}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           script or os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this pool (RCCL)
+    return subprocess.run(cmd, env=env).returncode
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -158,7 +179,16 @@ def main():
     ap.add_argument("--eager", action="store_true",
                     help="module-by-module path (spconv API, host syncs) instead of the "
                          "graph-captured FrameEngine")
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # not under a launcher: become the launcher (no GPU call has happened in this process)
+        if os.environ.get("LCF_REHEARSE") != "1" and torch.cuda.device_count() < args.gpus:
+            print(f"bench.py: --gpus {args.gpus} but only {torch.cuda.device_count()} GPU(s) are "
+                  "visible (LCF_REHEARSE=1 rehearses the control flow on one GPU over gloo)",
+                  file=sys.stderr)
+            return 2
+        return launch_ranks(args.gpus, argv)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -178,6 +208,10 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        world = dist.get_world_size()  # what the process group reports, not what was asked for
+    if world != args.gpus and rank == 0:
+        print(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s); reporting "
+              f"n_gpus = {world}", file=sys.stderr)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -187,6 +221,9 @@ def main():
     clouds_np = [gen(rank * args.frames + i, args.points)
                  for i in range(args.frames)]
     clouds = [torch.from_numpy(c).to(dev) for c in clouds_np]  # resident in HBM before timing
+    # the engine's capacities and kernel-selection hints are calibrated on OTHER frames of the
+    # same generator (seeds 100000+), never on the frames that are timed
+    calib = [torch.from_numpy(gen(100000 + rank * 4 + i, args.points)).to(dev) for i in range(4)]
 
     def barrier():
         if dist is not None:
@@ -197,14 +234,14 @@ def main():
         if args.eager:
             step = lambda c: model([c])
         else:
-            # one hipGraph replay per frame; capacities calibrated on this rank's frames
-            engine = model.engine(calib=clouds, conv_math=args.conv_math)
+            # one hipGraph replay per frame
+            engine = model.engine(calib=calib, conv_math=args.conv_math)
             step = engine.forward
             if args.inflight > 1:
                 # serving with several batch-1 requests in flight: one engine (own buffers, own
                 # graph) per slot, each on its own stream; frames alternate over the slots
                 streams = [torch.cuda.Stream(device=dev) for _ in range(args.inflight)]
-                engines = [engine] + [model.engine(calib=clouds, conv_math=args.conv_math)
+                engines = [engine] + [model.engine(calib=calib, conv_math=args.conv_math)
                                       for _ in range(args.inflight - 1)]
                 slot = [0]
 
@@ -246,7 +283,7 @@ def main():
                 and args.model != "M3"):
             alt = []
             for cm in ("bf16x8", "bf16x3"):
-                eng3 = model.engine(calib=clouds, conv_math=cm)
+                eng3 = model.engine(calib=calib, conv_math=cm)
                 for i in range(args.warmup):
                     eng3.forward(clouds[i % len(clouds)])
                 torch.cuda.synchronize()
@@ -301,7 +338,8 @@ def main():
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -58,6 +58,64 @@ def test_flat_allreduce_equals_single_process_average():
     assert torch.allclose(res[0][2], ref, rtol=1e-5, atol=1e-6)
 
 
+def _detector_worker(rank, world, port, q):
+    """The real Detector's parameters (SECOND front end + RPNV2, the bucket TrainStep owns) with
+    rank-dependent synthetic gradients: the sparse convs have no CPU path, so the gradients are
+    written, not computed -- what is under test is the bucket, its views and the exchange."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from objectdetection_amd.train import Detector
+    net = Detector("M2")
+    net.rpn.to(memory_format=torch.channels_last)  # as TrainStep does: strided gradient views
+    bucket = FlatGradAllReduce(net.parameters())
+    bucket.zero()
+    g = torch.Generator().manual_seed(100 + rank)
+    for p in net.parameters():
+        p.grad.copy_(torch.randn(p.shape, generator=g))
+    bucket.reduce()
+    named = dict(net.named_parameters())
+    names = ["frontend.middle_feature_extractor.middle_conv.0.weight", "rpn.blocks.0.1.weight",
+             "frontend.voxel_feature_extractor.vfe1.linear.weight"]
+    q.put((rank, bucket.flat.numel(), float(bucket.flat.double().sum()),
+           {n: named[n].grad.clone() for n in names},
+           all(p.grad.data_ptr() >= bucket.flat.data_ptr() and
+               p.grad.data_ptr() < bucket.flat.data_ptr() + bucket.flat.numel() * 4
+               for p in net.parameters())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_detector_bucket_allreduce_world2():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_detector_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][1] == res[1][1] > 1_800_000       # ~1.85 M parameters, one flat buffer
+    assert res[0][2] == res[1][2]                    # both ranks hold the same reduced bucket
+    assert res[0][4] and res[1][4]                   # every p.grad is a view into the bucket
+    from objectdetection_amd.train import Detector
+    net = Detector("M2")
+    net.rpn.to(memory_format=torch.channels_last)
+    want = {}
+    for rank in range(world):
+        g = torch.Generator().manual_seed(100 + rank)
+        for n, p in net.named_parameters():
+            r = torch.randn(p.shape, generator=g)
+            if n in res[0][3]:
+                want[n] = want.get(n, 0) + r / world
+    for n, w in want.items():
+        assert torch.allclose(res[0][3][n], w, rtol=1e-6, atol=1e-7), n
+        assert torch.equal(res[0][3][n], res[1][3][n])
+
+
 def test_shard_scenes_balances_cost():
     costs = [120, 20, 20, 20, 20, 20, 20, 20]
     shards = shard_scenes(costs, 2)
