@@ -36,6 +36,7 @@ extern "C" {
 #define LCF_ERR_UNSUPPORTED (-3) /* shape outside what the kernels are built for */
 #define LCF_ERR_RANGE (-4)       /* grid too large for 32-bit cell keys */
 #define LCF_ERR_LAUNCH (-5)      /* HIP reported a launch error */
+#define LCF_ERR_STATIC_LIMIT (-6) /* input larger than the no-allocation entry point's array */
 
 #define LCF_MAX_KVOL 64 /* kernel volume limit of the rulebook / conv kernels (3x3x3 = 27) */
 
@@ -95,6 +96,22 @@ int lcf_voxelize(const float *points, int n, const int *n_dev, int f, const floa
                  const float range[6], int max_pts, int max_vox, int cap_mode, int batch_idx,
                  int coor_stride, float *voxels, int *coors, int *num_pts, int *voxel_num,
                  void *ws, size_t ws_bytes, void *stream);
+
+/* lcf_voxelize without a workspace argument, for callers that CANNOT ALLOCATE device memory (code
+ * under hipGraph capture, tight serving loops, harnesses that forbid hipMalloc).  No counterpart
+ * in the reference.  The hash workspace lives in a file-scope device array of
+ * LCF_VOXELIZE_STATIC_BYTES (16 MiB, held by every GPU the library runs on until the process
+ * ends); the call allocates nothing and re-arms the array itself.  Inputs whose
+ * lcf_voxelize_workspace_bytes(n, max_pts) exceed the array (it holds n up to 262144 points at
+ * max_pts = 5, 32768 at max_pts = 35) return LCF_ERR_STATIC_LIMIT and run nothing.  All calls on
+ * one GPU share the array: calls that overlap on one GPU (two streams, two threads) race.
+ * Call it with the stream's device current.  Same outputs, bit for bit, as lcf_voxelize. */
+#define LCF_VOXELIZE_STATIC_BYTES (16u << 20)
+size_t lcf_voxelize_static_max_bytes(void);
+int lcf_voxelize_static(const float *points, int n, const int *n_dev, int f, const float vs[3],
+                        const float range[6], int max_pts, int max_vox, int cap_mode,
+                        int batch_idx, int coor_stride, float *voxels, int *coors, int *num_pts,
+                        int *voxel_num, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Rulebooks (spconv.ops.get_indice_pairs as called by SparseConvolution.forward for

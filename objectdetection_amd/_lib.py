@@ -26,6 +26,10 @@ SYMBOLS = {
     "lcf_voxelize": (c_int, [c_void_p, c_int, c_void_p, c_int, _PF, _PF, c_int, c_int, c_int,
                              c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                              c_size_t, c_void_p]),
+    "lcf_voxelize_static_max_bytes": (c_size_t, []),
+    "lcf_voxelize_static": (c_int, [c_void_p, c_int, c_void_p, c_int, _PF, _PF, c_int, c_int,
+                                    c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                    c_void_p]),
     "lcf_rulebook_subm_workspace_bytes": (c_size_t, [c_int]),
     "lcf_rulebook_subm_workspace_reset": (c_int, [c_void_p, c_size_t, c_int, c_void_p]),
     "lcf_rulebook_subm": (c_int, [c_void_p, c_int, c_void_p, c_int, _PI3, _PI3, _PI3, c_void_p,

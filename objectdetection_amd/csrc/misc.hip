@@ -10,6 +10,9 @@ extern "C" const char *lcf_strerror(int rc)
     case LCF_ERR_UNSUPPORTED: return "lcf: unsupported shape for the gfx950 kernels";
     case LCF_ERR_RANGE: return "lcf: grid or index range exceeds 32-bit keys";
     case LCF_ERR_LAUNCH: return "lcf: HIP launch error";
+    case LCF_ERR_STATIC_LIMIT:
+        return "lcf: input exceeds the static scratch array of the no-allocation entry point "
+               "(LCF_VOXELIZE_STATIC_BYTES); use lcf_voxelize with a caller workspace";
     default: return "lcf: unknown error";
     }
 }

@@ -16,6 +16,8 @@
 //               also writes coors / num_points and zero-fills the unused slots.
 #include "common.h"
 
+#include <mutex>
+
 #define VOX_SENT 0x7F7F7F7F /* list sentinel: byte-pattern memset, larger than any point index */
 #define VOX_ITEMS 4          /* points per thread in the count / assign kernels */
 #define VOX_BLOCK 256
@@ -240,11 +242,10 @@ extern "C" int lcf_voxelize_workspace_reset(void *ws, size_t ws_bytes, int n, in
     return vox_reset(w, max_pts, (hipStream_t)stream);
 }
 
-extern "C" int lcf_voxelize(const float *points, int n, const int *n_dev, int f,
-                            const float vs[3], const float range[6], int max_pts, int max_vox,
-                            int cap_mode, int batch_idx, int coor_stride, float *voxels,
-                            int *coors, int *num_pts, int *voxel_num, void *ws, size_t ws_bytes,
-                            void *stream)
+static int vox_run(const float *points, int n, const int *n_dev, int f, const float vs[3],
+                   const float range[6], int max_pts, int max_vox, int cap_mode, int batch_idx,
+                   int coor_stride, float *voxels, int *coors, int *num_pts, int *voxel_num,
+                   void *ws, size_t ws_bytes, bool reset, hipStream_t st)
 {
     if (n < 0 || f < 3 || max_pts <= 0 || max_vox <= 0 || !vs || !range || !voxels || !coors ||
         !num_pts || !voxel_num || !ws || (n > 0 && !points) || cap_mode < 0 || cap_mode > 1 ||
@@ -265,8 +266,7 @@ extern "C" int lcf_voxelize(const float *points, int n, const int *n_dev, int f,
     if (cells >= 0xFFFFFFFFull) return LCF_ERR_RANGE;
     VoxWs w = vox_carve(ws, n, max_pts);
     if (ws_bytes < w.bytes) return LCF_ERR_WORKSPACE;
-    hipStream_t st = (hipStream_t)stream;
-    if (!g_lcf_ws_clean && vox_reset(w, max_pts, st) != LCF_OK) return LCF_ERR_LAUNCH;
+    if (reset && vox_reset(w, max_pts, st) != LCF_OK) return LCF_ERR_LAUNCH;
     if (n > 0) {
         vox_insert_kernel<<<(n + VOX_BLOCK - 1) / VOX_BLOCK, VOX_BLOCK, 0, st>>>(
             points, n, n_dev, f, p, max_pts, w.keys, w.hc - 1, w.lists, w.cellslot);
@@ -284,4 +284,65 @@ extern "C" int lcf_voxelize(const float *points, int n, const int *n_dev, int f,
         w.cellslot, w.pvid, w.ctrl, voxel_num, voxels, coors, num_pts);
     LCF_CHECK_LAUNCH();
     return LCF_OK;
+}
+
+extern "C" int lcf_voxelize(const float *points, int n, const int *n_dev, int f,
+                            const float vs[3], const float range[6], int max_pts, int max_vox,
+                            int cap_mode, int batch_idx, int coor_stride, float *voxels,
+                            int *coors, int *num_pts, int *voxel_num, void *ws, size_t ws_bytes,
+                            void *stream)
+{
+    return vox_run(points, n, n_dev, f, vs, range, max_pts, max_vox, cap_mode, batch_idx,
+                   coor_stride, voxels, coors, num_pts, voxel_num, ws, ws_bytes, !g_lcf_ws_clean,
+                   (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------- the entry point that allocates
+// nothing: lcf_voxelize with its hash workspace in a file-scope device array instead of a caller
+// buffer, for callers that cannot allocate (code under hipGraph capture, tight serving loops,
+// harnesses that forbid hipMalloc).  Every GPU the library runs on holds its own copy of the
+// array until the process ends; all calls on one GPU share it (overlapping calls race).
+static __device__ __align__(256) unsigned char scratch[LCF_VOXELIZE_STATIC_BYTES];
+
+#define VOX_MAX_DEVICES 64
+static void *g_scratch_ptr[VOX_MAX_DEVICES]; // device address of `scratch`, per device
+static std::mutex g_scratch_mu;
+
+// The array's name is a host-side stand-in, not a device address: resolve the address once per
+// device, with that device current, and use only the resolved pointer afterwards.
+static int vox_scratch(void **out)
+{
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= VOX_MAX_DEVICES)
+        return LCF_ERR_LAUNCH;
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    if (!g_scratch_ptr[dev]) {
+        void *ptr = nullptr;
+        if (hipGetSymbolAddress((void **)&ptr, HIP_SYMBOL(scratch)) != hipSuccess || !ptr)
+            return LCF_ERR_LAUNCH;
+        g_scratch_ptr[dev] = ptr;
+    }
+    *out = g_scratch_ptr[dev];
+    return LCF_OK;
+}
+
+extern "C" size_t lcf_voxelize_static_max_bytes(void) { return LCF_VOXELIZE_STATIC_BYTES; }
+
+extern "C" int lcf_voxelize_static(const float *points, int n, const int *n_dev, int f,
+                                   const float vs[3], const float range[6], int max_pts,
+                                   int max_vox, int cap_mode, int batch_idx, int coor_stride,
+                                   float *voxels, int *coors, int *num_pts, int *voxel_num,
+                                   void *stream)
+{
+    if (n < 0 || max_pts <= 0) return LCF_ERR_ARG;
+    // sizes beyond the array: a clear error, never a partial run
+    if (lcf_voxelize_workspace_bytes(n, max_pts) > (size_t)LCF_VOXELIZE_STATIC_BYTES)
+        return LCF_ERR_STATIC_LIMIT;
+    void *ptr = nullptr;
+    int rc = vox_scratch(&ptr);
+    if (rc != LCF_OK) return rc;
+    // the array keeps the previous call's contents: always re-armed here (reset = true)
+    return vox_run(points, n, n_dev, f, vs, range, max_pts, max_vox, cap_mode, batch_idx,
+                   coor_stride, voxels, coors, num_pts, voxel_num, ptr,
+                   (size_t)LCF_VOXELIZE_STATIC_BYTES, true, (hipStream_t)stream);
 }
