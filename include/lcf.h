@@ -8,6 +8,8 @@
  *   - The caller (PyTorch host side) owns every buffer: inputs, outputs, workspaces.  No entry
  *     point allocates or frees device memory, none synchronises the device; all work is
  *     enqueued on `stream` (a hipStream_t passed as void*; NULL = the legacy default stream).
+ *   - Re-entrant: all state lives in caller buffers and in the caller's lcf_ctx (options, open
+ *     fill batch), passed as the LAST argument where an entry point has options (NULL = defaults).
  *   - Return 0 on success, a negative LCF_ERR_* otherwise; lcf_strerror() names it.
  *   - Data-dependent sizes (number of voxels, number of active outputs) come back through
  *     device int32 scalars; the caller passes capacities.
@@ -43,35 +45,59 @@ extern "C" {
 const char *lcf_strerror(int rc);
 int lcf_version(void);
 
-/* Process-wide tuning options (no counterpart in the reference).
- * LCF_OPT_CONV_SPLIT: how many waves share one 16-row tile of the indice_conv forward by
- * splitting its output columns: 1, 2 or 4; 0 (default) = choose from the row count. */
+/* ------------------------------------------------------------------------------------------
+ * Options and contexts (no counterpart in the reference).
+ *
+ * The library is re-entrant: nothing an entry point does depends on process-wide mutable state.
+ * Every option travels in an lcf_ctx -- an opaque HOST object the caller creates, owns and passes
+ * (as the last argument) to the entry points that have options; NULL = all defaults.  One context
+ * must not be used by two threads at once; different contexts (e.g. one per FrameEngine, one per
+ * thread) never interact.  A context also carries the caller's open fill batch (below).
+ *
+ * Options (lcf_ctx_set_option; 0 = default):
+ * LCF_OPT_CONV_SPLIT: how many waves share one 16-row tile of the slab-form indice_conv forward
+ *   by splitting its output columns: 1, 2 or 4; 0 = choose from the row count.
+ * LCF_OPT_CONV_IMPL: forward kernel: 0 = per shape (tile-compacted when both channel counts are
+ *   >= 32, split-slab for thin layers with <= 32 output channels, slab form for the rest),
+ *   1 = slab form wherever it applies, 2 = tile-compacted, 3 = split-slab wherever it applies.
+ * LCF_OPT_CONV_TILE: output rows per workgroup of the tile-compacted forward: 16..32, or 0 = the
+ *   largest height <= 32 that deals the tiles evenly over the 256 CUs.
+ * LCF_OPT_CONV_SETS: wave sets per workgroup of the tile-compacted forward (a second set takes
+ *   every other kernel offset of the tile): 1, 2 or 0 = two when every tile of the launch is
+ *   resident at once, judged from the rows the launch expects.
+ * LCF_OPT_CONV_ROWS_HINT: the number of output rows the forward calls made with this context
+ *   expect, for callers that pass a capacity as k_out and keep the real count on the device; only
+ *   kernel selection reads it (never bounds).  0 = use the k_out passed to the call.
+ * LCF_OPT_WS_CLEAN: 1 = lcf_voxelize, lcf_rulebook_subm and lcf_rulebook_conv_discover skip the
+ *   reset of their hash workspace: the caller guarantees it is in the reset state on entry
+ *   (lcf_*_workspace_reset, e.g. enqueued behind the previous frame, off its critical path); the
+ *   calls leave it dirty.  0 = every call resets its workspace itself.
+ * LCF_OPT_NBR_CLEAN: 1 = lcf_rulebook_conv_fill skips filling out_nbr / in_nbr with -1: the
+ *   caller has done it (e.g. all tables of a frame in one batched fill).
+ *
+ * lcf_set_option() sets process-wide DEFAULTS of the four kernel-selection knobs only (SPLIT,
+ * IMPL, TILE, SETS; what a context leaves at 0 takes the default) -- for benchmarks and tests that
+ * pin a kernel variant.  It rejects ROWS_HINT, WS_CLEAN and NBR_CLEAN (LCF_ERR_ARG): those change
+ * what a call assumes about the caller's buffers and exist per context only. */
 #define LCF_OPT_CONV_SPLIT 0
-/* LCF_OPT_CONV_IMPL: forward kernel: 0 (default) = per shape (tile-compacted when both channel
- * counts are >= 32, split-slab for thin layers with <= 32 output channels, slab form for the
- * rest), 1 = slab form wherever it applies, 2 = tile-compacted, 3 = split-slab wherever it
- * applies (<= 32 output channels). */
 #define LCF_OPT_CONV_IMPL 1
-/* LCF_OPT_CONV_TILE: output rows per workgroup of the tile-compacted forward: 16..32, or 0
- * (default) = the largest height <= 32 that deals the tiles evenly over the 256 CUs. */
 #define LCF_OPT_CONV_TILE 2
-/* LCF_OPT_CONV_SETS: wave sets per workgroup of the tile-compacted forward (a second set takes
- * every other kernel offset of the tile): 1, 2 or 0 (default) = two when every tile of the
- * launch is resident at once, judged from the row capacity passed to the call. */
 #define LCF_OPT_CONV_SETS 3
-/* LCF_OPT_CONV_ROWS_HINT: the number of output rows the following forward calls expect, for
- * callers that pass a capacity as k_out and keep the real count on the device; only kernel
- * selection reads it (never bounds).  0 (default) = use the k_out passed to the call. */
 #define LCF_OPT_CONV_ROWS_HINT 4
-/* LCF_OPT_WS_CLEAN: 1 = lcf_voxelize, lcf_rulebook_subm and lcf_rulebook_conv_discover skip the
- * reset of their hash workspace: the caller guarantees it is in the reset state on entry
- * (lcf_*_workspace_reset below, e.g. enqueued behind the previous frame, off its critical path);
- * the calls leave it dirty.  0 (default) = every call resets its workspace itself. */
 #define LCF_OPT_WS_CLEAN 5
-/* LCF_OPT_NBR_CLEAN: 1 = lcf_rulebook_conv_fill skips filling out_nbr / in_nbr with -1: the
- * caller has done it (e.g. all tables of a frame in one lcf_fill_batch launch).  Default 0. */
 #define LCF_OPT_NBR_CLEAN 6
+typedef struct lcf_ctx lcf_ctx;
+int lcf_ctx_create(lcf_ctx **out);
+void lcf_ctx_destroy(lcf_ctx *ctx);
+int lcf_ctx_set_option(lcf_ctx *ctx, int option, int value);
 int lcf_set_option(int option, int value);
+
+/* Batched fills: between lcf_ctx_fill_batch_begin(ctx) and lcf_ctx_fill_batch_flush(ctx, stream)
+ * the fills that lcf_fill_u32 and the lcf_*_workspace_reset calls would launch WHEN GIVEN THIS
+ * CONTEXT are recorded in it (their stream argument is ignored) and the flush runs all of them
+ * as ONE kernel on `stream`.  Calls without the context, or with another one, are unaffected. */
+int lcf_ctx_fill_batch_begin(lcf_ctx *ctx);
+int lcf_ctx_fill_batch_flush(lcf_ctx *ctx, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Voxelization.
@@ -91,11 +117,12 @@ int lcf_set_option(int option, int value);
  */
 size_t lcf_voxelize_workspace_bytes(int n, int max_pts);
 /* Puts a workspace of lcf_voxelize(n, max_pts) into its reset state (see LCF_OPT_WS_CLEAN). */
-int lcf_voxelize_workspace_reset(void *ws, size_t ws_bytes, int n, int max_pts, void *stream);
+int lcf_voxelize_workspace_reset(void *ws, size_t ws_bytes, int n, int max_pts, void *stream,
+                                 lcf_ctx *ctx);
 int lcf_voxelize(const float *points, int n, const int *n_dev, int f, const float vs[3],
                  const float range[6], int max_pts, int max_vox, int cap_mode, int batch_idx,
                  int coor_stride, float *voxels, int *coors, int *num_pts, int *voxel_num,
-                 void *ws, size_t ws_bytes, void *stream);
+                 void *ws, size_t ws_bytes, void *stream, lcf_ctx *ctx);
 
 /* lcf_voxelize without a workspace argument, for callers that CANNOT ALLOCATE device memory (code
  * under hipGraph capture, tight serving loops, harnesses that forbid hipMalloc).  No counterpart
@@ -126,12 +153,16 @@ int lcf_voxelize_static(const float *points, int n, const int *n_dev, int f, con
  * bit-identical to spconv's CPU get_indice_pairs.
  *
  * coors [k,4] i32 (b,z,y,x).  shape/ksize/stride/pad/dil are HOST int[3] (z,y,x order).
+ * Limits (LCF_ERR_RANGE beyond): fewer than 2^25 rows on either side of a rulebook (the conv
+ * kernels pack a gathered row id into 25 bits), k_in * prod(ceil(ksize/stride)) < 2^30, and
+ * batch * D * H * W < 2^32 - 1 cells.
  */
 size_t lcf_rulebook_subm_workspace_bytes(int k);
-int lcf_rulebook_subm_workspace_reset(void *ws, size_t ws_bytes, int k, void *stream);
+int lcf_rulebook_subm_workspace_reset(void *ws, size_t ws_bytes, int k, void *stream,
+                                      lcf_ctx *ctx);
 int lcf_rulebook_subm(const int *coors, int k, const int *k_dev, int batch, const int shape[3],
                       const int ksize[3], const int dil[3], int *out_nbr, void *ws,
-                      size_t ws_bytes, void *stream);
+                      size_t ws_bytes, void *stream, lcf_ctx *ctx);
 
 /* Strided / ordinary sparse conv, two phases.  Either the caller reads *k_out between them to
  * size the tables exactly (as spconv synchronises to size its output), or it passes capacities
@@ -148,16 +179,17 @@ void lcf_conv_out_shape(const int shape[3], const int ksize[3], const int stride
                         const int pad[3], const int dil[3], int out_shape[3]);
 size_t lcf_rulebook_conv_workspace_bytes(int k_in, const int ksize[3], const int stride[3]);
 int lcf_rulebook_conv_workspace_reset(void *ws, size_t ws_bytes, int k_in, const int ksize[3],
-                                      const int stride[3], void *stream);
+                                      const int stride[3], void *stream, lcf_ctx *ctx);
 int lcf_rulebook_conv_discover(const int *coors, int k_in, const int *k_in_dev, int batch,
                                const int shape[3], const int ksize[3], const int stride[3],
                                const int pad[3], const int dil[3], int *out_coors, int cap_out,
                                int *k_out, int *overflow, void *ws, size_t ws_bytes,
-                               void *stream);
+                               void *stream, lcf_ctx *ctx);
 int lcf_rulebook_conv_fill(const int *coors, int k_in, const int *k_in_dev, int batch,
                            const int shape[3], const int ksize[3], const int stride[3],
                            const int pad[3], const int dil[3], int k_out, const int *k_out_dev,
-                           int *out_nbr, int *in_nbr, void *ws, size_t ws_bytes, void *stream);
+                           int *out_nbr, int *in_nbr, void *ws, size_t ws_bytes, void *stream,
+                           lcf_ctx *ctx);
 
 /* mirror a submanifold table: in_nbr[j][o] = out_nbr[j][kvol-1-o] */
 int lcf_rulebook_mirror(const int *nbr, int k, int kvol, int *mirrored, void *stream);
@@ -188,7 +220,7 @@ int lcf_weight_image(const float *w, int kvol, int cin, int cout, int transpose,
                      void *stream);
 int lcf_indice_conv_fwd(const float *feat, const float *wimg, const int *nbr, int k_out,
                         const int *k_out_dev, int kvol, int cin, int cout, const float *scale,
-                        const float *shift, int relu, float *out, void *stream);
+                        const float *shift, int relu, float *out, void *stream, lcf_ctx *ctx);
 /* bf16-operand variant (BASELINE.json configs[2]: "bf16 MFMA indice_conv" for training): the
  * features stay fp32 in HBM and are rounded to bf16 when they enter LDS, the weights come as a
  * bf16 image (lcf_weight_image_bf16: kvol*cin*cout 2-byte elements in
@@ -200,7 +232,7 @@ int lcf_weight_image_bf16(const float *w, int kvol, int cin, int cout, int trans
 int lcf_indice_conv_fwd_bf16(const float *feat, const void *wimg_bf16, const int *nbr, int k_out,
                              const int *k_out_dev, int kvol, int cin, int cout,
                              const float *scale, const float *shift, int relu, float *out,
-                             void *stream);
+                             void *stream, lcf_ctx *ctx);
 /* Split-operand variant ("bf16x3") of the fp32 forward, for inference at fp32 tolerance on the
  * bf16 matrix cores: every fp32 operand is x = hi + lo, hi = bf16(x), lo = bf16(x - hi)
  * (|x - hi - lo| <= 2^-18 |x|); features are split when they enter LDS, the weights come as a
@@ -218,7 +250,7 @@ int lcf_indice_conv_fwd_bf16x3(const float *feat, const void *wimg_bf16x3, const
                                int k_out, const int *k_out_dev, int kvol, int cin, int cout,
                                const float *scale, const float *shift, int relu, float *out,
                                const int *dense_coors, int batch, const int shape[3],
-                               void *stream);
+                               void *stream, lcf_ctx *ctx);
 /* Three-plane form of the same ("bf16x8"): x = hi + mid + lo exactly (three bf16 planes, 8 + 8 + 8
  * significand bits) and the eight products down to 2^-24 |a||w| -- what is dropped (lo*lo, 2^-32)
  * is far below the rounding of fp32 operands' own products, so results are fp32-grade (measured:
@@ -231,7 +263,7 @@ int lcf_indice_conv_fwd_bf16x8(const float *feat, const void *wimg_bf16x8, const
                                int k_out, const int *k_out_dev, int kvol, int cin, int cout,
                                const float *scale, const float *shift, int relu, float *out,
                                const int *dense_coors, int batch, const int shape[3],
-                               void *stream);
+                               void *stream, lcf_ctx *ctx);
 /* fwd with SparseConvTensor.dense() (second/pytorch/models/middle.py:206, right after the last
  * SparseConv3d + BatchNorm1d + ReLU of the stack, :186-192) fused into its epilogue: instead of
  * out[row,:] the result lands in dense[b, :, z, y, x] of a [batch, cout, D, H, W] f32 tensor,
@@ -244,7 +276,7 @@ int lcf_indice_conv_fwd_dense(const float *feat, const float *wimg, const int *n
                               const int *k_out_dev, int kvol, int cin, int cout,
                               const float *scale, const float *shift, int relu,
                               const int *out_coors, int batch, const int shape[3], float *dense,
-                              void *stream);
+                              void *stream, lcf_ctx *ctx);
 int lcf_indice_conv_wgrad(const float *feat, const float *dout, const int *in_nbr, int k_in,
                           int kvol, int cin, int cout, float *dw, void *stream);
 
@@ -265,14 +297,6 @@ int lcf_indice_conv_wgrad_bf16(const float *feat, const float *dout, const int *
                                int kvol, int cin, int cout, int planes, float *dw,
                                void *stream);
 
-/* Batched fills (no counterpart in the reference; process-wide state like lcf_set_option, not
- * thread-safe): between lcf_fill_batch_begin() and lcf_fill_batch_flush(stream) the fills that
- * lcf_fill_u32 and the lcf_*_workspace_reset calls would launch are recorded (their stream
- * argument is ignored) and the flush runs all of them as ONE kernel on `stream`.  Any other entry
- * point must not be called in between. */
-int lcf_fill_batch_begin(void);
-int lcf_fill_batch_flush(void *stream);
-
 /* Frame hand-over for a caller that keeps a static point buffer and a device-side point count
  * (FrameEngine; no counterpart in the reference): dst[0 : n*f] = points[0 : n*f] and
  * n_dev[0] = n_total (>= n: dst may point behind points already in the buffer, the light-curtain
@@ -283,7 +307,7 @@ int lcf_load_points(const float *points, int n, int f, float *dst, int n_total, 
 
 /* Fill `bytes` (multiple of 4, 4-byte aligned) with a 32-bit pattern: a plain kernel, usable
  * where hipMemsetAsync is not wanted (graph capture; no counterpart in the reference). */
-int lcf_fill_u32(void *p, uint32_t value, size_t bytes, void *stream);
+int lcf_fill_u32(void *p, uint32_t value, size_t bytes, void *stream, lcf_ctx *ctx);
 
 /* ------------------------------------------------------------------------------------------
  * SparseConvTensor.dense() (second/pytorch/models/middle.py:206): out [B,C,D,H,W] f32 is

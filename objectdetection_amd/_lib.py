@@ -21,30 +21,37 @@ SYMBOLS = {
     "lcf_strerror": (ctypes.c_char_p, [c_int]),
     "lcf_version": (c_int, []),
     "lcf_set_option": (c_int, [c_int, c_int]),
+    "lcf_ctx_create": (c_int, [ctypes.POINTER(c_void_p)]),
+    "lcf_ctx_destroy": (None, [c_void_p]),
+    "lcf_ctx_set_option": (c_int, [c_void_p, c_int, c_int]),
+    "lcf_ctx_fill_batch_begin": (c_int, [c_void_p]),
+    "lcf_ctx_fill_batch_flush": (c_int, [c_void_p, c_void_p]),
     "lcf_voxelize_workspace_bytes": (c_size_t, [c_int, c_int]),
-    "lcf_voxelize_workspace_reset": (c_int, [c_void_p, c_size_t, c_int, c_int, c_void_p]),
+    "lcf_voxelize_workspace_reset": (c_int, [c_void_p, c_size_t, c_int, c_int, c_void_p,
+                                             c_void_p]),
     "lcf_voxelize": (c_int, [c_void_p, c_int, c_void_p, c_int, _PF, _PF, c_int, c_int, c_int,
                              c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                             c_size_t, c_void_p]),
+                             c_size_t, c_void_p, c_void_p]),
     "lcf_voxelize_static_max_bytes": (c_size_t, []),
     "lcf_voxelize_static": (c_int, [c_void_p, c_int, c_void_p, c_int, _PF, _PF, c_int, c_int,
                                     c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_void_p]),
     "lcf_rulebook_subm_workspace_bytes": (c_size_t, [c_int]),
-    "lcf_rulebook_subm_workspace_reset": (c_int, [c_void_p, c_size_t, c_int, c_void_p]),
+    "lcf_rulebook_subm_workspace_reset": (c_int, [c_void_p, c_size_t, c_int, c_void_p,
+                                                  c_void_p]),
     "lcf_rulebook_subm": (c_int, [c_void_p, c_int, c_void_p, c_int, _PI3, _PI3, _PI3, c_void_p,
-                                  c_void_p, c_size_t, c_void_p]),
+                                  c_void_p, c_size_t, c_void_p, c_void_p]),
     "lcf_rulebook_conv_max_out": (c_int, [c_int, _PI3, _PI3]),
     "lcf_conv_out_shape": (None, [_PI3, _PI3, _PI3, _PI3, _PI3, _PI3]),
     "lcf_rulebook_conv_workspace_bytes": (c_size_t, [c_int, _PI3, _PI3]),
     "lcf_rulebook_conv_workspace_reset": (c_int, [c_void_p, c_size_t, c_int, _PI3, _PI3,
-                                                  c_void_p]),
+                                                  c_void_p, c_void_p]),
     "lcf_rulebook_conv_discover": (c_int, [c_void_p, c_int, c_void_p, c_int, _PI3, _PI3, _PI3,
                                            _PI3, _PI3, c_void_p, c_int, c_void_p, c_void_p,
-                                           c_void_p, c_size_t, c_void_p]),
+                                           c_void_p, c_size_t, c_void_p, c_void_p]),
     "lcf_rulebook_conv_fill": (c_int, [c_void_p, c_int, c_void_p, c_int, _PI3, _PI3, _PI3, _PI3,
                                        _PI3, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
-                                       c_size_t, c_void_p]),
+                                       c_size_t, c_void_p, c_void_p]),
     "lcf_rulebook_mirror": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "lcf_rulebook_pairs_workspace_bytes": (c_size_t, [c_int, c_int]),
     "lcf_rulebook_pairs": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p,
@@ -52,31 +59,30 @@ SYMBOLS = {
     "lcf_weight_image_elems": (c_size_t, [c_int, c_int, c_int, c_int]),
     "lcf_weight_image": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "lcf_indice_conv_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int,
-                                    c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+                                    c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
+                                    c_void_p]),
     "lcf_weight_image_bf16": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "lcf_indice_conv_fwd_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int,
                                          c_int, c_int, c_void_p, c_void_p, c_int, c_void_p,
-                                         c_void_p]),
+                                         c_void_p, c_void_p]),
     "lcf_weight_image_bf16x3": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p,
                                         c_void_p]),
     "lcf_indice_conv_fwd_bf16x3": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int,
                                            c_int, c_int, c_void_p, c_void_p, c_int, c_void_p,
-                                           c_void_p, c_int, _PI3, c_void_p]),
+                                           c_void_p, c_int, _PI3, c_void_p, c_void_p]),
     "lcf_weight_image_bf16x8": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p,
                                         c_void_p]),
     "lcf_indice_conv_fwd_bf16x8": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int,
                                            c_int, c_int, c_void_p, c_void_p, c_int, c_void_p,
-                                           c_void_p, c_int, _PI3, c_void_p]),
+                                           c_void_p, c_int, _PI3, c_void_p, c_void_p]),
     "lcf_indice_conv_fwd_dense": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int,
                                           c_int, c_int, c_void_p, c_void_p, c_int, c_void_p,
-                                          c_int, _PI3, c_void_p, c_void_p]),
+                                          c_int, _PI3, c_void_p, c_void_p, c_void_p]),
     "lcf_indice_conv_wgrad": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                       c_void_p, c_void_p]),
     "lcf_linear_wgrad": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "lcf_indice_conv_wgrad_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                            c_int, c_int, c_void_p, c_void_p]),
-    "lcf_fill_batch_begin": (c_int, []),
-    "lcf_fill_batch_flush": (c_int, [c_void_p]),
     "lcf_load_points": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     "lcf_dense": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, _PI3, c_int,
                           c_void_p, c_void_p]),
@@ -97,7 +103,7 @@ SYMBOLS = {
                                 c_void_p]),
     "lcf_vfe_pool": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p,
                              c_void_p, c_int, c_void_p, c_void_p]),
-    "lcf_fill_u32": (c_int, [c_void_p, ctypes.c_uint32, c_size_t, c_void_p]),
+    "lcf_fill_u32": (c_int, [c_void_p, ctypes.c_uint32, c_size_t, c_void_p, c_void_p]),
     "lcf_vfe_fused": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int,
                               c_int] + [c_void_p] * 11),
     "lcf_rotate_iou": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p,
@@ -112,6 +118,38 @@ SYMBOLS = {
                                 c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
                                 c_void_p]),
 }
+
+# entry points whose LAST argument is the caller's lcf_ctx (NULL = defaults): the binding lets
+# Python callers omit it
+CTX_LAST = {"lcf_voxelize", "lcf_voxelize_workspace_reset", "lcf_rulebook_subm",
+            "lcf_rulebook_subm_workspace_reset", "lcf_rulebook_conv_workspace_reset",
+            "lcf_rulebook_conv_discover", "lcf_rulebook_conv_fill", "lcf_indice_conv_fwd",
+            "lcf_indice_conv_fwd_bf16", "lcf_indice_conv_fwd_bf16x3",
+            "lcf_indice_conv_fwd_bf16x8", "lcf_indice_conv_fwd_dense", "lcf_fill_u32"}
+
+
+class _Lib:
+    """The loaded CDLL with every declared symbol bound; calls to a CTX_LAST entry point made
+    without the trailing context get NULL for it."""
+
+    def __init__(self, cdll):
+        self._cdll = cdll
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(cdll, name)  # AttributeError if the ABI is incomplete
+            fn.restype = res
+            fn.argtypes = args
+            if name in CTX_LAST:
+                fn = self._optional_ctx(fn, len(args))
+            setattr(self, name, fn)
+
+    @staticmethod
+    def _optional_ctx(fn, nargs):
+        def call(*a):
+            if len(a) == nargs - 1:
+                a = a + (None,)
+            return fn(*a)
+        return call
+
 
 # lcf_set_option keys (include/lcf.h)
 OPT_CONV_SPLIT, OPT_CONV_IMPL, OPT_CONV_TILE, OPT_CONV_SETS, OPT_CONV_ROWS_HINT = 0, 1, 2, 3, 4
@@ -137,13 +175,33 @@ def lib():
                 f"{LIB_PATH} not found: build it with "
                 "`python -c 'import __graft_entry__ as g; g.build()'` or "
                 "`make -C objectdetection_amd/csrc`.  There is no CPU fallback.")
-        l = ctypes.CDLL(LIB_PATH)
-        for name, (res, args) in SYMBOLS.items():
-            fn = getattr(l, name)  # AttributeError if the ABI is incomplete
-            fn.restype = res
-            fn.argtypes = args
-        _lib = l
+        _lib = _Lib(ctypes.CDLL(LIB_PATH))
     return _lib
+
+
+class Context:
+    """A caller-owned lcf_ctx (include/lcf.h): per-call options and the open fill batch.  One per
+    enqueueing thread / engine; pass ``ctx.handle`` as the last argument of the entry points that
+    have options.  Destroyed with the Python object."""
+
+    def __init__(self):
+        h = c_void_p()
+        check(lib().lcf_ctx_create(ctypes.byref(h)))
+        self.handle = h
+
+    def set(self, option, value):
+        check(lib().lcf_ctx_set_option(self.handle, int(option), int(value)))
+
+    def fill_batch_begin(self):
+        check(lib().lcf_ctx_fill_batch_begin(self.handle))
+
+    def fill_batch_flush(self, stream):
+        check(lib().lcf_ctx_fill_batch_flush(self.handle, stream))
+
+    def __del__(self):
+        h, self.handle = getattr(self, "handle", None), None
+        if h and _lib is not None:
+            _lib.lcf_ctx_destroy(h)
 
 
 def check(rc):

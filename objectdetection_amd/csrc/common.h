@@ -18,17 +18,68 @@
 // and `p` 4-byte aligned (every workspace region is 256-byte aligned).
 __global__ void lcf_fill32_kernel(uint32_t *p, uint32_t v, size_t n32);
 int lcf_fill32(void *p, uint32_t v, size_t bytes, hipStream_t st);
-// LCF_OPT_WS_CLEAN: the caller hands in workspaces already in their reset state (misc.hip)
-extern int g_lcf_ws_clean;
-// LCF_OPT_NBR_CLEAN: lcf_rulebook_conv_fill's neighbour tables arrive filled with -1 (misc.hip)
-extern int g_lcf_nbr_clean;
+
+// ---- per-call options.  The caller owns an lcf_ctx (include/lcf.h) and passes it to the entry
+// points that have options; nothing here is process-global except the four kernel-selection
+// DEFAULTS that lcf_set_option keeps for benchmarks and tests (atomics, read once per call).
+struct LcfOpts {
+    int conv_split, conv_impl, conv_tile, conv_sets; // kernel selection (0 = choose)
+    int rows_hint;                                   // expected rows of the next conv launches
+    int ws_clean, nbr_clean;                         // caller-guaranteed buffer states
+};
+#define LCF_FILL_MAX_SEGS 16
+struct LcfFillSeg {
+    uint32_t *p;
+    uint32_t v;
+    unsigned blk0; // first workgroup of the segment
+    unsigned long long n32;
+};
+struct LcfFillPlan {
+    LcfFillSeg s[LCF_FILL_MAX_SEGS];
+    int n;
+};
+struct lcf_ctx {
+    LcfOpts o;
+    LcfFillPlan plan; // fills recorded between lcf_ctx_fill_batch_begin and _flush
+    int batching;
+    unsigned fill_blocks;
+};
+// options of the call in progress on this thread (set by LcfCall for the duration of one entry
+// point; host helpers deep in the launch code read them without having them threaded through)
+extern thread_local const LcfOpts *t_lcf_opts;
+LcfOpts lcf_default_opts(); // process-wide defaults (lcf_set_option)
+struct LcfCall {
+    LcfOpts eff;
+    const LcfOpts *prev;
+    explicit LcfCall(const lcf_ctx *c)
+    {
+        eff = lcf_default_opts();
+        if (c) {
+            if (c->o.conv_split) eff.conv_split = c->o.conv_split;
+            if (c->o.conv_impl) eff.conv_impl = c->o.conv_impl;
+            if (c->o.conv_tile) eff.conv_tile = c->o.conv_tile;
+            if (c->o.conv_sets) eff.conv_sets = c->o.conv_sets;
+            eff.rows_hint = c->o.rows_hint;
+            eff.ws_clean = c->o.ws_clean;
+            eff.nbr_clean = c->o.nbr_clean;
+        }
+        prev = t_lcf_opts;
+        t_lcf_opts = &eff;
+    }
+    ~LcfCall() { t_lcf_opts = prev; }
+    LcfCall(const LcfCall &) = delete;
+    LcfCall &operator=(const LcfCall &) = delete;
+};
+static inline LcfOpts lcf_opts() { return t_lcf_opts ? *t_lcf_opts : lcf_default_opts(); }
+// a fill that joins the context's batch when one is open, else launches now
+int lcf_fill32_ctx(lcf_ctx *ctx, void *p, uint32_t v, size_t bytes, hipStream_t st);
 
 static inline size_t lcf_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 static inline uint32_t lcf_pow2_ge(uint32_t x)
 {
     uint32_t p = 1;
-    while (p < x) p <<= 1;
+    while (p < x && p < 0x80000000u) p <<= 1; // clamps at 2^31: never loops on overflow
     return p;
 }
 

@@ -14,6 +14,8 @@
 #include <stdlib.h>
 
 #include "common.h"
+
+#include <mutex>
 #include <type_traits>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -1008,9 +1010,10 @@ cv_tc_kernel(const float *__restrict__ feat, const float *__restrict__ wimg,
     }
 }
 
-static int g_tc_rows = 0; // LCF_OPT_CONV_TILE: 0 = balance over the CUs, 16..32 = fixed height
-static int g_tc_sets = 0; // LCF_OPT_CONV_SETS: 0 = choose from the row count, 1 or 2 wave sets
-static int g_rows_hint = 0; // LCF_OPT_CONV_ROWS_HINT: expected rows (0 = the capacity passed)
+// Launch-time choices come from the options of the call in progress (lcf_opts(), common.h):
+// conv_tile (LCF_OPT_CONV_TILE: 0 = balance over the CUs, 16..32 = fixed height), conv_sets
+// (LCF_OPT_CONV_SETS: 0 = choose from the row count, 1 or 2 wave sets), rows_hint
+// (LCF_OPT_CONV_ROWS_HINT: expected rows, 0 = the capacity passed).
 
 template <int CIN, int COUT, int TR, bool BF16 = false, int NSETS = 1, int NP = 1>
 static int cv_launch_tc_n(const float *feat, const float *wimg, const int *nbr, int k_cap,
@@ -1023,6 +1026,8 @@ static int cv_launch_tc_n(const float *feat, const float *wimg, const int *nbr, 
     size_t lds = tc_lds_bytes(CIN, COUT, TR, kvol, BF16, NSETS, NP);
     if (lds > 160 * 1024) return LCF_ERR_UNSUPPORTED;
     static size_t lds_set = 0; // per instantiation: largest dynamic LDS size opted into so far
+    static std::mutex lds_mu;  // two threads' first launches must not interleave set + record
+    std::unique_lock<std::mutex> lds_lock(lds_mu);
     if (lds > 64 * 1024 && lds > lds_set) {
         if (hipFuncSetAttribute((const void *)cv_tc_kernel<CIN, COUT, TR, true, BF16, NSETS, NP>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1036,6 +1041,7 @@ static int cv_launch_tc_n(const float *feat, const float *wimg, const int *nbr, 
         }
         lds_set = lds;
     }
+    lds_lock.unlock();
     if (tr < 1 || tr > TR) return LCF_ERR_ARG;
     if (dn.coors && cout != COUT) return LCF_ERR_UNSUPPORTED;
     int nb = (k_cap + tr - 1) / tr;
@@ -1059,7 +1065,8 @@ static int cv_launch_tc_n(const float *feat, const float *wimg, const int *nbr, 
 // long as the CUs with 3; 744 tiles of 25 rows are 3 everywhere, each 22% shorter).
 static int tc_tile_rows(int rows)
 {
-    if (g_tc_rows >= 16 && g_tc_rows <= 32) return g_tc_rows;
+    const int fixed = lcf_opts().conv_tile;
+    if (fixed >= 16 && fixed <= 32) return fixed;
     const int per_round = 256;
     const int m = (rows + per_round * 32 - 1) / (per_round * 32); // tiles per CU at 32 rows
     if (m < 1) return 32;
@@ -1090,9 +1097,11 @@ static int cv_launch_tc(const float *feat, const float *wimg, const int *nbr, in
 {
     // tiles of up to 32 rows: measured against 64-row tiles on every SECOND layer (half the
     // workgroups with the same serial chain lose)
-    const int rows = g_rows_hint > 0 && g_rows_hint < k_cap ? g_rows_hint : k_cap;
+    const LcfOpts op = lcf_opts();
+    const int rows = op.rows_hint > 0 && op.rows_hint < k_cap ? op.rows_hint : k_cap;
     const int tr = tc_tile_rows(rows);
-    const bool two = g_tc_sets == 2 || (g_tc_sets == 0 && tc_two_sets_fit(CIN, COUT, kvol, rows, tr));
+    const bool two = op.conv_sets == 2 ||
+                     (op.conv_sets == 0 && tc_two_sets_fit(CIN, COUT, kvol, rows, tr));
     if (two && tc_lds_bytes(CIN, COUT, 32, kvol, false, 2) <= 160 * 1024)
         return cv_launch_tc_n<CIN, COUT, 32, false, 2>(feat, wimg, nbr, k_cap, k_dev, kvol, cin,
                                                        cout, scale, shift, relu, out, st, tr, dn);
@@ -1156,8 +1165,9 @@ static int cv_launch_tc_bf16(const float *feat, const float *wimg, const int *nb
 extern "C" int lcf_indice_conv_fwd_bf16(const float *feat, const void *wimg_bf16, const int *nbr,
                                         int k_out, const int *k_out_dev, int kvol, int cin,
                                         int cout, const float *scale, const float *shift,
-                                        int relu, float *out, void *stream)
+                                        int relu, float *out, void *stream, lcf_ctx *ctx)
 {
+    LcfCall call(ctx);
     if (k_out < 0 || kvol <= 0 || !wimg_bf16 || (k_out > 0 && (!feat || !out)) ||
         (!nbr && kvol != 1))
         return LCF_ERR_ARG;
@@ -1245,11 +1255,12 @@ static int cv_launch_tc_split(const float *feat, const float *wimg, const int *n
                               const float *shift, int relu, float *out, hipStream_t st,
                               TcDense dn)
 {
-    const int rows = g_rows_hint > 0 && g_rows_hint < k_cap ? g_rows_hint : k_cap;
+    const LcfOpts op = lcf_opts();
+    const int rows = op.rows_hint > 0 && op.rows_hint < k_cap ? op.rows_hint : k_cap;
     const int tr = tc_tile_rows(rows);
     // three planes: a second wave set never paid (tools/bench_conv.py: 42 vs 50 us at 18.6k rows)
-    const bool two = g_tc_sets == 2 || (g_tc_sets == 0 && NP < 3 &&
-                                        tc_two_sets_fit(CIN, COUT, kvol, rows, tr, true, NP));
+    const bool two = op.conv_sets == 2 || (op.conv_sets == 0 && NP < 3 &&
+                                           tc_two_sets_fit(CIN, COUT, kvol, rows, tr, true, NP));
     if (two && tc_lds_bytes(CIN, COUT, 32, kvol, true, 2, NP) <= 160 * 1024)
         return cv_launch_tc_n<CIN, COUT, 32, true, 2, NP>(feat, wimg, nbr, k_cap, k_dev, kvol, cin,
                                                           cout, scale, shift, relu, out, st, tr,
@@ -1296,8 +1307,9 @@ extern "C" int lcf_indice_conv_fwd_bf16x3(const float *feat, const void *wimg_bf
                                           int kvol, int cin, int cout, const float *scale,
                                           const float *shift, int relu, float *out,
                                           const int *dense_coors, int batch, const int shape[3],
-                                          void *stream)
+                                          void *stream, lcf_ctx *ctx)
 {
+    LcfCall call(ctx);
     return cv_fwd_split(feat, wimg_bf16x3, nbr, k_out, k_out_dev, kvol, cin, cout, scale, shift,
                         relu, out, dense_coors, batch, shape, stream, 2);
 }
@@ -1307,8 +1319,9 @@ extern "C" int lcf_indice_conv_fwd_bf16x8(const float *feat, const void *wimg_bf
                                           int kvol, int cin, int cout, const float *scale,
                                           const float *shift, int relu, float *out,
                                           const int *dense_coors, int batch, const int shape[3],
-                                          void *stream)
+                                          void *stream, lcf_ctx *ctx)
 {
+    LcfCall call(ctx);
     return cv_fwd_split(feat, wimg_bf16x8, nbr, k_out, k_out_dev, kvol, cin, cout, scale, shift,
                         relu, out, dense_coors, batch, shape, stream, 3);
 }
@@ -1647,12 +1660,19 @@ static int cv_launch_fwd_n(const float *feat, const float *wimg, const int *nbr,
     constexpr int ROWS = 16 * CV_WAVES / NSPLIT;
     size_t lds = (size_t)2 * CIN * COUT * 4 + (size_t)ROWS * kvol * 4 + (size_t)kvol * 4 + 16;
     int nb = (k_out + ROWS - 1) / ROWS;
-    if (lds > 64 * 1024) {
-        // more than the 64 KiB default: opt in (gfx950 has 160 KiB of LDS per CU)
-        if (hipFuncSetAttribute((const void *)cv_fwd_kernel<CIN, COUT, NSPLIT>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds) != hipSuccess)
-            return LCF_ERR_LAUNCH;
+    {
+        // more than the 64 KiB default: opt in (gfx950 has 160 KiB of LDS per CU); monotonic per
+        // instantiation and under a lock, so that two threads' launches cannot lower it
+        static size_t lds_set = 0;
+        static std::mutex lds_mu;
+        std::lock_guard<std::mutex> lock(lds_mu);
+        if (lds > 64 * 1024 && lds > lds_set) {
+            if (hipFuncSetAttribute((const void *)cv_fwd_kernel<CIN, COUT, NSPLIT>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lds) != hipSuccess)
+                return LCF_ERR_LAUNCH;
+            lds_set = lds;
+        }
     }
     cv_fwd_kernel<CIN, COUT, NSPLIT><<<nb, CV_BLOCK, lds, st>>>(
         feat, wimg, nbr, k_out, k_dev, kvol, cin, cout, scale, shift, relu, out);
@@ -1660,50 +1680,8 @@ static int cv_launch_fwd_n(const float *feat, const float *wimg, const int *nbr,
     return LCF_OK;
 }
 
-// Tuning knob (lcf_set_option(LCF_OPT_CONV_SPLIT, 1|2|4)); 0 = pick by size.
-static int g_conv_split = 0;
-static int g_conv_impl = 0; // 0 = choose per shape, 1 = slab, 2 = tile-compacted, 3 = split-slab
-static int cv_split_override() { return g_conv_split; }
-
-extern "C" int lcf_set_option(int option, int value)
-{
-    if (option == LCF_OPT_CONV_SPLIT) {
-        if (value != 0 && value != 1 && value != 2 && value != 4) return LCF_ERR_ARG;
-        g_conv_split = value;
-        return LCF_OK;
-    }
-    if (option == LCF_OPT_CONV_IMPL) {
-        if (value < 0 || value > 3) return LCF_ERR_ARG;
-        g_conv_impl = value;
-        return LCF_OK;
-    }
-    if (option == LCF_OPT_WS_CLEAN) {
-        if (value != 0 && value != 1) return LCF_ERR_ARG;
-        g_lcf_ws_clean = value;
-        return LCF_OK;
-    }
-    if (option == LCF_OPT_NBR_CLEAN) {
-        if (value != 0 && value != 1) return LCF_ERR_ARG;
-        g_lcf_nbr_clean = value;
-        return LCF_OK;
-    }
-    if (option == LCF_OPT_CONV_ROWS_HINT) {
-        if (value < 0) return LCF_ERR_ARG;
-        g_rows_hint = value;
-        return LCF_OK;
-    }
-    if (option == LCF_OPT_CONV_SETS) {
-        if (value < 0 || value > 2) return LCF_ERR_ARG;
-        g_tc_sets = value;
-        return LCF_OK;
-    }
-    if (option == LCF_OPT_CONV_TILE) {
-        if (value != 0 && (value < 16 || value > 32)) return LCF_ERR_ARG;
-        g_tc_rows = value;
-        return LCF_OK;
-    }
-    return LCF_ERR_ARG;
-}
+// Tuning knob LCF_OPT_CONV_SPLIT (1|2|4; 0 = pick by size) of the call in progress.
+static int cv_split_override() { return lcf_opts().conv_split; }
 
 template <int CIN, int COUT>
 static int cv_launch_fwd(const float *feat, const float *wimg, const int *nbr, int k_out,
@@ -1763,8 +1741,10 @@ static int cv_launch_fwd(const float *feat, const float *wimg, const int *nbr, i
 extern "C" int lcf_indice_conv_fwd(const float *feat, const float *wimg, const int *nbr,
                                    int k_out, const int *k_out_dev, int kvol, int cin, int cout,
                                    const float *scale, const float *shift, int relu, float *out,
-                                   void *stream)
+                                   void *stream, lcf_ctx *ctx)
 {
+    LcfCall call(ctx);
+    const int g_conv_impl = call.eff.conv_impl;
     if (k_out < 0 || kvol <= 0 || cin <= 0 || cout <= 0 || !wimg ||
         (k_out > 0 && (!feat || !out)) || (!nbr && kvol != 1))
         return LCF_ERR_ARG;
@@ -1772,7 +1752,9 @@ extern "C" int lcf_indice_conv_fwd(const float *feat, const float *wimg, const i
     if (((uintptr_t)feat & 15) || ((uintptr_t)wimg & 15) || ((uintptr_t)out & 15) ||
         ((uintptr_t)scale & 15) || ((uintptr_t)shift & 15))
         return LCF_ERR_ARG;
-    if (k_out >= (1 << 26)) return LCF_ERR_RANGE; // compacted entries pack row << 6 | lane
+    // compacted entries pack (input row << 7 | tile row) in 32 bits: rows < 2^25 on both sides
+    // (the rulebook builders refuse to build tables over more input rows than that)
+    if (k_out >= (1 << 25)) return LCF_ERR_RANGE;
     int CIN = cv_pad_cin(cin), COUT = cv_pad_cout(cout);
     if (CIN < 0 || COUT < 0) return LCF_ERR_UNSUPPORTED;
     if (k_out == 0) return LCF_OK;
@@ -1798,8 +1780,10 @@ extern "C" int lcf_indice_conv_fwd_dense(const float *feat, const float *wimg, c
                                          int k_out, const int *k_out_dev, int kvol, int cin,
                                          int cout, const float *scale, const float *shift,
                                          int relu, const int *out_coors, int batch,
-                                         const int shape[3], float *dense, void *stream)
+                                         const int shape[3], float *dense, void *stream,
+                                         lcf_ctx *ctx)
 {
+    LcfCall call(ctx);
     if (k_out < 0 || kvol <= 0 || cin <= 0 || cout <= 0 || !wimg || !nbr || !shape ||
         batch <= 0 || (k_out > 0 && (!feat || !dense || !out_coors)))
         return LCF_ERR_ARG;
@@ -1807,7 +1791,7 @@ extern "C" int lcf_indice_conv_fwd_dense(const float *feat, const float *wimg, c
     if (((uintptr_t)feat & 15) || ((uintptr_t)wimg & 15) || ((uintptr_t)out_coors & 15) ||
         ((uintptr_t)scale & 15) || ((uintptr_t)shift & 15))
         return LCF_ERR_ARG;
-    if (k_out >= (1 << 26)) return LCF_ERR_RANGE;
+    if (k_out >= (1 << 25)) return LCF_ERR_RANGE;
     int CIN = cv_pad_cin(cin), COUT = cv_pad_cout(cout);
     if (CIN < 0 || COUT < 0 || COUT != cout) return LCF_ERR_UNSUPPORTED;
     if (k_out == 0) return LCF_OK;

@@ -35,35 +35,106 @@ __global__ void __launch_bounds__(256) lcf_fill32_kernel(uint32_t *p, uint32_t v
     if (t < n32 - tail0) p[tail0 + t] = v;
 }
 
-int g_lcf_ws_clean = 0;
-int g_lcf_nbr_clean = 0;
+// ---------------------------------------------------------------- contexts and options
+#include <atomic>
+#include <new>
 
-// Batched fills: between lcf_fill_batch_begin() and lcf_fill_batch_flush() every fill the library
-// would launch (workspace resets, lcf_fill_u32) is recorded instead, and the flush runs them as
-// ONE kernel -- the engine re-arms ten hash workspaces and clears the dense output behind a
-// frame's rulebook branch: eleven 4-5 us launches there become one.
-#define FILL_MAX_SEGS 16
-struct FillSeg {
-    uint32_t *p;
-    uint32_t v;
-    unsigned blk0; // first workgroup of the segment
-    unsigned long long n32;
-};
-struct FillPlan {
-    FillSeg s[FILL_MAX_SEGS];
-    int n;
-};
-static FillPlan g_fill_plan;
-static int g_fill_batching = 0;
-static unsigned g_fill_blocks = 0;
+thread_local const LcfOpts *t_lcf_opts = nullptr;
+static std::atomic<int> g_def_split{0}, g_def_impl{0}, g_def_tile{0}, g_def_sets{0};
 
-__global__ void __launch_bounds__(256) lcf_fill32_multi_kernel(FillPlan plan)
+LcfOpts lcf_default_opts()
+{
+    LcfOpts o{};
+    o.conv_split = g_def_split.load(std::memory_order_relaxed);
+    o.conv_impl = g_def_impl.load(std::memory_order_relaxed);
+    o.conv_tile = g_def_tile.load(std::memory_order_relaxed);
+    o.conv_sets = g_def_sets.load(std::memory_order_relaxed);
+    return o;
+}
+
+static int opt_store(int option, int value, int *split, int *impl, int *tile, int *sets)
+{
+    switch (option) {
+    case LCF_OPT_CONV_SPLIT:
+        if (value != 0 && value != 1 && value != 2 && value != 4) return LCF_ERR_ARG;
+        *split = value;
+        return LCF_OK;
+    case LCF_OPT_CONV_IMPL:
+        if (value < 0 || value > 3) return LCF_ERR_ARG;
+        *impl = value;
+        return LCF_OK;
+    case LCF_OPT_CONV_TILE:
+        if (value != 0 && (value < 16 || value > 32)) return LCF_ERR_ARG;
+        *tile = value;
+        return LCF_OK;
+    case LCF_OPT_CONV_SETS:
+        if (value < 0 || value > 2) return LCF_ERR_ARG;
+        *sets = value;
+        return LCF_OK;
+    default: return LCF_ERR_ARG;
+    }
+}
+
+// Process-wide DEFAULTS of the four kernel-selection knobs only (benchmarks, tests).  The options
+// that change what a call assumes about its buffers (WS_CLEAN, NBR_CLEAN) and the rows hint are
+// per context: a process-wide switch for them would change the behaviour of other threads' calls.
+extern "C" int lcf_set_option(int option, int value)
+{
+    int split = g_def_split, impl = g_def_impl, tile = g_def_tile, sets = g_def_sets;
+    int rc = opt_store(option, value, &split, &impl, &tile, &sets);
+    if (rc != LCF_OK) return rc;
+    g_def_split = split;
+    g_def_impl = impl;
+    g_def_tile = tile;
+    g_def_sets = sets;
+    return LCF_OK;
+}
+
+extern "C" int lcf_ctx_create(lcf_ctx **out)
+{
+    if (!out) return LCF_ERR_ARG;
+    lcf_ctx *c = new (std::nothrow) lcf_ctx();
+    if (!c) return LCF_ERR_ARG;
+    *out = c;
+    return LCF_OK;
+}
+
+extern "C" void lcf_ctx_destroy(lcf_ctx *ctx) { delete ctx; }
+
+extern "C" int lcf_ctx_set_option(lcf_ctx *ctx, int option, int value)
+{
+    if (!ctx) return LCF_ERR_ARG;
+    switch (option) {
+    case LCF_OPT_WS_CLEAN:
+        if (value != 0 && value != 1) return LCF_ERR_ARG;
+        ctx->o.ws_clean = value;
+        return LCF_OK;
+    case LCF_OPT_NBR_CLEAN:
+        if (value != 0 && value != 1) return LCF_ERR_ARG;
+        ctx->o.nbr_clean = value;
+        return LCF_OK;
+    case LCF_OPT_CONV_ROWS_HINT:
+        if (value < 0) return LCF_ERR_ARG;
+        ctx->o.rows_hint = value;
+        return LCF_OK;
+    default:
+        return opt_store(option, value, &ctx->o.conv_split, &ctx->o.conv_impl, &ctx->o.conv_tile,
+                         &ctx->o.conv_sets);
+    }
+}
+
+// Batched fills: between lcf_ctx_fill_batch_begin() and lcf_ctx_fill_batch_flush() every fill the
+// library would launch FOR THIS CONTEXT (workspace resets, lcf_fill_u32) is recorded in the
+// context instead, and the flush runs them as ONE kernel -- the engine re-arms ten hash
+// workspaces and clears the dense output behind a frame's rulebook branch: eleven 4-5 us launches
+// there become one.
+__global__ void __launch_bounds__(256) lcf_fill32_multi_kernel(LcfFillPlan plan)
 {
     int i = 0;
 #pragma unroll 1
     for (int j = 1; j < plan.n; ++j)
         if (blockIdx.x >= plan.s[j].blk0) i = j;
-    const FillSeg sg = plan.s[i];
+    const LcfFillSeg sg = plan.s[i];
     const unsigned nblk = (i + 1 < plan.n ? plan.s[i + 1].blk0 : gridDim.x) - sg.blk0;
     uint32_t *p = sg.p;
     const size_t n32 = sg.n32;
@@ -80,28 +151,30 @@ __global__ void __launch_bounds__(256) lcf_fill32_multi_kernel(FillPlan plan)
     if (t < n32 - tail0) p[tail0 + t] = sg.v;
 }
 
-static int fill_plan_launch(hipStream_t st)
+static int fill_plan_launch(lcf_ctx *ctx, hipStream_t st)
 {
-    if (g_fill_plan.n == 0) return LCF_OK;
-    lcf_fill32_multi_kernel<<<g_fill_blocks, 256, 0, st>>>(g_fill_plan);
-    g_fill_plan.n = 0;
-    g_fill_blocks = 0;
+    if (ctx->plan.n == 0) return LCF_OK;
+    lcf_fill32_multi_kernel<<<ctx->fill_blocks, 256, 0, st>>>(ctx->plan);
+    ctx->plan.n = 0;
+    ctx->fill_blocks = 0;
     LCF_CHECK_LAUNCH();
     return LCF_OK;
 }
 
-extern "C" int lcf_fill_batch_begin(void)
+extern "C" int lcf_ctx_fill_batch_begin(lcf_ctx *ctx)
 {
-    g_fill_plan.n = 0;
-    g_fill_blocks = 0;
-    g_fill_batching = 1;
+    if (!ctx) return LCF_ERR_ARG;
+    ctx->plan.n = 0;
+    ctx->fill_blocks = 0;
+    ctx->batching = 1;
     return LCF_OK;
 }
 
-extern "C" int lcf_fill_batch_flush(void *stream)
+extern "C" int lcf_ctx_fill_batch_flush(lcf_ctx *ctx, void *stream)
 {
-    g_fill_batching = 0;
-    return fill_plan_launch((hipStream_t)stream);
+    if (!ctx) return LCF_ERR_ARG;
+    ctx->batching = 0;
+    return fill_plan_launch(ctx, (hipStream_t)stream);
 }
 
 int lcf_fill32(void *p, uint32_t v, size_t bytes, hipStream_t st)
@@ -109,22 +182,6 @@ int lcf_fill32(void *p, uint32_t v, size_t bytes, hipStream_t st)
     if (bytes == 0) return LCF_OK;
     if ((bytes & 3) || ((uintptr_t)p & 3)) return LCF_ERR_ARG;
     size_t n32 = bytes / 4;
-    if (g_fill_batching) {
-        if (g_fill_plan.n == FILL_MAX_SEGS) { // full: run what is recorded so far
-            int rc = fill_plan_launch(st);
-            if (rc != LCF_OK) return rc;
-        }
-        size_t nbs = (n32 / 4 + 255) / 256;
-        if (nbs < 1) nbs = 1;
-        if (nbs > 2048) nbs = 2048;
-        FillSeg &sg = g_fill_plan.s[g_fill_plan.n++];
-        sg.p = (uint32_t *)p;
-        sg.v = v;
-        sg.blk0 = g_fill_blocks;
-        sg.n32 = n32;
-        g_fill_blocks += (unsigned)nbs;
-        return LCF_OK;
-    }
     size_t nb = (n32 / 4 + 255) / 256;
     if (nb < 1) nb = 1;
     if (nb > 4096) nb = 4096;
@@ -133,10 +190,32 @@ int lcf_fill32(void *p, uint32_t v, size_t bytes, hipStream_t st)
     return LCF_OK;
 }
 
-extern "C" int lcf_fill_u32(void *p, uint32_t value, size_t bytes, void *stream)
+int lcf_fill32_ctx(lcf_ctx *ctx, void *p, uint32_t v, size_t bytes, hipStream_t st)
+{
+    if (!ctx || !ctx->batching) return lcf_fill32(p, v, bytes, st);
+    if (bytes == 0) return LCF_OK;
+    if ((bytes & 3) || ((uintptr_t)p & 3)) return LCF_ERR_ARG;
+    if (ctx->plan.n == LCF_FILL_MAX_SEGS) { // full: run what is recorded so far
+        int rc = fill_plan_launch(ctx, st);
+        if (rc != LCF_OK) return rc;
+    }
+    const size_t n32 = bytes / 4;
+    size_t nbs = (n32 / 4 + 255) / 256;
+    if (nbs < 1) nbs = 1;
+    if (nbs > 2048) nbs = 2048;
+    LcfFillSeg &sg = ctx->plan.s[ctx->plan.n++];
+    sg.p = (uint32_t *)p;
+    sg.v = v;
+    sg.blk0 = ctx->fill_blocks;
+    sg.n32 = n32;
+    ctx->fill_blocks += (unsigned)nbs;
+    return LCF_OK;
+}
+
+extern "C" int lcf_fill_u32(void *p, uint32_t value, size_t bytes, void *stream, lcf_ctx *ctx)
 {
     if (!p && bytes) return LCF_ERR_ARG;
-    return lcf_fill32(p, value, bytes, (hipStream_t)stream);
+    return lcf_fill32_ctx(ctx, p, value, bytes, (hipStream_t)stream);
 }
 
 // ---------------------------------------------------------------- frame hand-over

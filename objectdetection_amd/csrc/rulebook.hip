@@ -364,32 +364,35 @@ static uint32_t rb_capacity(long long items)
 {
     long long need = items * 2;
     if (need < 1024) need = 1024;
+    if (need > 0x80000000ll) need = 0x80000000ll; // callers reject such sizes (LCF_ERR_RANGE)
     return lcf_pow2_ge((uint32_t)need);
 }
 
 extern "C" size_t lcf_rulebook_subm_workspace_bytes(int k)
 {
-    if (k < 0) return 0;
+    if (k < 0 || k >= 0x3FFFFFFF) return 0;
     uint32_t hc = rb_capacity(k);
     return lcf_align_up((size_t)hc * 4, 256) * 2;
 }
 
 extern "C" int lcf_rulebook_subm(const int *coors, int k, const int *k_dev, int batch,
                                  const int shape[3], const int ksize[3], const int dil[3],
-                                 int *out_nbr, void *ws, size_t ws_bytes, void *stream)
+                                 int *out_nbr, void *ws, size_t ws_bytes, void *stream,
+                                 lcf_ctx *ctx)
 {
     if (k < 0 || (k > 0 && (!coors || !out_nbr)) || !ws) return LCF_ERR_ARG;
     ConvGeom g;
     int rc = rb_geom(&g, batch, shape, ksize, nullptr, nullptr, dil, true);
     if (rc) return rc;
-    if ((long long)k * g.kvol >= 0x7FFFFFFFll) return LCF_ERR_RANGE;
+    // rows < 2^25: what the conv kernels' packed gather entries can address (conv.hip)
+    if ((long long)k * g.kvol >= 0x7FFFFFFFll || k >= (1 << 25)) return LCF_ERR_RANGE;
     if (ws_bytes < lcf_rulebook_subm_workspace_bytes(k)) return LCF_ERR_WORKSPACE;
     if (k == 0) return LCF_OK;
     uint32_t hc = rb_capacity(k);
     uint32_t *keys = (uint32_t *)ws;
     int *vals = (int *)((char *)ws + lcf_align_up((size_t)hc * 4, 256));
     hipStream_t st = (hipStream_t)stream;
-    if (!g_lcf_ws_clean && lcf_fill32(keys, 0xFFFFFFFFu, (size_t)hc * 4, st) != LCF_OK)
+    if (!(ctx && ctx->o.ws_clean) && lcf_fill32(keys, 0xFFFFFFFFu, (size_t)hc * 4, st) != LCF_OK)
         return LCF_ERR_LAUNCH;
     rb_subm_insert_kernel<<<(k + RB_BLOCK - 1) / RB_BLOCK, RB_BLOCK, 0, st>>>(
         coors, k, k_dev, batch, g, keys, hc - 1, vals);
@@ -401,11 +404,12 @@ extern "C" int lcf_rulebook_subm(const int *coors, int k, const int *k_dev, int 
     return LCF_OK;
 }
 
-extern "C" int lcf_rulebook_subm_workspace_reset(void *ws, size_t ws_bytes, int k, void *stream)
+extern "C" int lcf_rulebook_subm_workspace_reset(void *ws, size_t ws_bytes, int k, void *stream,
+                                                 lcf_ctx *ctx)
 {
     if (!ws || k < 0) return LCF_ERR_ARG;
     if (ws_bytes < lcf_rulebook_subm_workspace_bytes(k)) return LCF_ERR_WORKSPACE;
-    return lcf_fill32(ws, 0xFFFFFFFFu, (size_t)rb_capacity(k) * 4, (hipStream_t)stream);
+    return lcf_fill32_ctx(ctx, ws, 0xFFFFFFFFu, (size_t)rb_capacity(k) * 4, (hipStream_t)stream);
 }
 
 extern "C" int lcf_rulebook_mirror(const int *nbr, int k, int kvol, int *mirrored, void *stream)
@@ -466,12 +470,13 @@ extern "C" size_t lcf_rulebook_conv_workspace_bytes(int k_in, const int ksize[3]
         if (ksize[d] <= 0 || stride[d] <= 0) return 0;
         e *= (ksize[d] + stride[d] - 1) / stride[d];
     }
+    if ((long long)k_in * e >= 0x3FFFFFFFll) return 0; // LCF_ERR_RANGE at the call
     return rb_conv_carve(nullptr, k_in, (int)e).bytes;
 }
 
 extern "C" int lcf_rulebook_conv_workspace_reset(void *ws, size_t ws_bytes, int k_in,
                                                  const int ksize[3], const int stride[3],
-                                                 void *stream)
+                                                 void *stream, lcf_ctx *ctx)
 {
     if (!ws || k_in < 0 || !ksize || !stride) return LCF_ERR_ARG;
     long long e = 1;
@@ -479,9 +484,10 @@ extern "C" int lcf_rulebook_conv_workspace_reset(void *ws, size_t ws_bytes, int 
         if (ksize[d] <= 0 || stride[d] <= 0) return LCF_ERR_ARG;
         e *= (ksize[d] + stride[d] - 1) / stride[d];
     }
+    if ((long long)k_in * e >= 0x3FFFFFFFll) return LCF_ERR_RANGE;
     ConvWs w = rb_conv_carve(ws, k_in, (int)e);
     if (ws_bytes < w.bytes) return LCF_ERR_WORKSPACE;
-    return lcf_fill32(w.tab, 0xFFFFFFFFu, (size_t)w.hc * 8, (hipStream_t)stream);
+    return lcf_fill32_ctx(ctx, w.tab, 0xFFFFFFFFu, (size_t)w.hc * 8, (hipStream_t)stream);
 }
 
 extern "C" int lcf_rulebook_conv_discover(const int *coors, int k_in, const int *k_in_dev,
@@ -489,15 +495,16 @@ extern "C" int lcf_rulebook_conv_discover(const int *coors, int k_in, const int 
                                           const int stride[3], const int pad[3],
                                           const int dil[3], int *out_coors, int cap_out,
                                           int *k_out, int *overflow, void *ws, size_t ws_bytes,
-                                          void *stream)
+                                          void *stream, lcf_ctx *ctx)
 {
     if (k_in < 0 || !stride || !pad || !k_out || !ws || (k_in > 0 && (!coors || !out_coors)))
         return LCF_ERR_ARG;
     ConvGeom g;
     int rc = rb_geom(&g, batch, shape, ksize, stride, pad, dil, false);
     if (rc) return rc;
+    // 32-bit stamps and a 2x table; rows < 2^25 (the conv kernels' packed gather entries)
+    if ((long long)k_in * g.E >= 0x3FFFFFFFll || k_in >= (1 << 25)) return LCF_ERR_RANGE;
     ConvWs w = rb_conv_carve(ws, k_in, g.E);
-    if (w.total >= 0x7FFFFFFFll) return LCF_ERR_RANGE;
     if (ws_bytes < w.bytes) return LCF_ERR_WORKSPACE;
     if (cap_out < 0 || (!overflow && cap_out < lcf_rulebook_conv_max_out(k_in, ksize, stride)))
         return LCF_ERR_ARG; // a capacity below the worst case needs somewhere to report overflow
@@ -506,7 +513,8 @@ extern "C" int lcf_rulebook_conv_discover(const int *coors, int k_in, const int 
         if (lcf_fill32(k_out, 0u, 4, st) != LCF_OK) return LCF_ERR_LAUNCH;
         return LCF_OK;
     }
-    if (!g_lcf_ws_clean && lcf_fill32(w.tab, 0xFFFFFFFFu, (size_t)w.hc * 8, st) != LCF_OK)
+    if (!(ctx && ctx->o.ws_clean) &&
+        lcf_fill32(w.tab, 0xFFFFFFFFu, (size_t)w.hc * 8, st) != LCF_OK)
         return LCF_ERR_LAUNCH;
     unsigned nb = (unsigned)((w.total + RB_BLOCK - 1) / RB_BLOCK);
     rb_conv_insert_kernel<<<nb, RB_BLOCK, 0, st>>>(coors, k_in, k_in_dev, batch, g, w.tab,
@@ -526,7 +534,8 @@ extern "C" int lcf_rulebook_conv_fill(const int *coors, int k_in, const int *k_i
                                       const int shape[3], const int ksize[3],
                                       const int stride[3], const int pad[3], const int dil[3],
                                       int k_out, const int *k_out_dev, int *out_nbr,
-                                      int *in_nbr, void *ws, size_t ws_bytes, void *stream)
+                                      int *in_nbr, void *ws, size_t ws_bytes, void *stream,
+                                      lcf_ctx *ctx)
 {
     if (k_in < 0 || k_out < 0 || !stride || !pad || !ws || (k_in > 0 && !coors) ||
         (k_out > 0 && !out_nbr))
@@ -534,10 +543,11 @@ extern "C" int lcf_rulebook_conv_fill(const int *coors, int k_in, const int *k_i
     ConvGeom g;
     int rc = rb_geom(&g, batch, shape, ksize, stride, pad, dil, false);
     if (rc) return rc;
+    if ((long long)k_in * g.E >= 0x3FFFFFFFll) return LCF_ERR_RANGE;
     ConvWs w = rb_conv_carve(ws, k_in, g.E);
     if (ws_bytes < w.bytes) return LCF_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
-    if (!g_lcf_nbr_clean) { // LCF_OPT_NBR_CLEAN: the caller has filled both tables with -1
+    if (!(ctx && ctx->o.nbr_clean)) { // LCF_OPT_NBR_CLEAN: the caller filled both tables with -1
         if (k_out > 0 &&
             lcf_fill32(out_nbr, 0xFFFFFFFFu, (size_t)k_out * g.kvol * 4, st) != LCF_OK)
             return LCF_ERR_LAUNCH;

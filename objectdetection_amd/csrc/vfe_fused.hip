@@ -23,6 +23,8 @@
 // up to fp32 summation order.
 #include "common.h"
 
+#include <mutex>
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define VF_V 16       /* voxels per group */
@@ -272,13 +274,17 @@ extern "C" int lcf_vfe_fused(const float *voxels, const int *num, int k, const i
         ((uintptr_t)w3img & 15))
         return LCF_ERR_ARG;
     if (k == 0) return LCF_OK;
-    static size_t lds_set = 0;
-    if (lds > 64 * 1024 && lds > lds_set) {
-        if (hipFuncSetAttribute((const void *)vfe_fused_kernel,
-                                hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds) != hipSuccess)
-            return LCF_ERR_LAUNCH;
-        lds_set = lds;
+    {
+        static size_t lds_set = 0;
+        static std::mutex lds_mu; // two threads' first launches must not interleave set + record
+        std::lock_guard<std::mutex> lock(lds_mu);
+        if (lds > 64 * 1024 && lds > lds_set) {
+            if (hipFuncSetAttribute((const void *)vfe_fused_kernel,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lds) != hipSuccess)
+                return LCF_ERR_LAUNCH;
+            lds_set = lds;
+        }
     }
     int ngroups = (k + VF_V - 1) / VF_V;
     int per_cu = (int)((160 * 1024) / lds);

@@ -225,21 +225,22 @@ extern "C" size_t lcf_voxelize_workspace_bytes(int n, int max_pts)
     return vox_carve(nullptr, n, max_pts).bytes;
 }
 
-static int vox_reset(const VoxWs &w, int max_pts, hipStream_t st)
+static int vox_reset(const VoxWs &w, int max_pts, hipStream_t st, lcf_ctx *ctx = nullptr)
 {
-    if (lcf_fill32(w.keys, 0xFFFFFFFFu, (size_t)w.hc * 4, st) != LCF_OK) return LCF_ERR_LAUNCH;
-    if (lcf_fill32(w.lists, (uint32_t)VOX_SENT, (size_t)w.hc * max_pts * 4, st) != LCF_OK)
+    if (lcf_fill32_ctx(ctx, w.keys, 0xFFFFFFFFu, (size_t)w.hc * 4, st) != LCF_OK)
+        return LCF_ERR_LAUNCH;
+    if (lcf_fill32_ctx(ctx, w.lists, (uint32_t)VOX_SENT, (size_t)w.hc * max_pts * 4, st) != LCF_OK)
         return LCF_ERR_LAUNCH;
     return LCF_OK;
 }
 
 extern "C" int lcf_voxelize_workspace_reset(void *ws, size_t ws_bytes, int n, int max_pts,
-                                            void *stream)
+                                            void *stream, lcf_ctx *ctx)
 {
     if (!ws || n < 0 || max_pts <= 0) return LCF_ERR_ARG;
     VoxWs w = vox_carve(ws, n, max_pts);
     if (ws_bytes < w.bytes) return LCF_ERR_WORKSPACE;
-    return vox_reset(w, max_pts, (hipStream_t)stream);
+    return vox_reset(w, max_pts, (hipStream_t)stream, ctx);
 }
 
 static int vox_run(const float *points, int n, const int *n_dev, int f, const float vs[3],
@@ -290,10 +291,11 @@ extern "C" int lcf_voxelize(const float *points, int n, const int *n_dev, int f,
                             const float vs[3], const float range[6], int max_pts, int max_vox,
                             int cap_mode, int batch_idx, int coor_stride, float *voxels,
                             int *coors, int *num_pts, int *voxel_num, void *ws, size_t ws_bytes,
-                            void *stream)
+                            void *stream, lcf_ctx *ctx)
 {
+    const bool ws_clean = ctx && ctx->o.ws_clean;
     return vox_run(points, n, n_dev, f, vs, range, max_pts, max_vox, cap_mode, batch_idx,
-                   coor_stride, voxels, coors, num_pts, voxel_num, ws, ws_bytes, !g_lcf_ws_clean,
+                   coor_stride, voxels, coors, num_pts, voxel_num, ws, ws_bytes, !ws_clean,
                    (hipStream_t)stream);
 }
 

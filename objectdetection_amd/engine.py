@@ -18,8 +18,11 @@ Every internal buffer reset is a fill KERNEL (lcf_fill32), not hipMemsetAsync: o
 captured graph holding hipMemsetAsync nodes hung at its second replay on this path.
 
 Capacities of the strided levels are calibrated on sample frames (x ``margin``); a frame that
-exceeds them sets a device flag, reported by ``check()`` (``forward(..., sync=True)`` re-plans
-with larger capacities and re-runs the frame on its own).
+exceeds them sets a device flag, reported by ``check()`` (``forward(..., sync=True)`` measures the
+frame with loose capacities, re-plans from what it needs and re-runs it, once).
+
+Thread safety: an engine owns its lcf_ctx (options, fill batch) and its buffers; two engines may
+enqueue from two threads.  One engine is not meant to be driven from two threads at once.
 """
 import os
 
@@ -64,6 +67,11 @@ class FrameEngine:
             raise RuntimeError("FrameEngine folds BatchNorm: put the model in eval() mode")
         self.model = model
         self.L = _lib.lib()
+        # this engine's own context (include/lcf.h: lcf_ctx): the options its calls run with and
+        # its open fill batch live here, never in process-wide state, so engines enqueueing from
+        # different threads (or beside plain ops.* callers) do not see each other
+        self.ctx = _lib.Context()
+        self._ws_dirty = False  # an enqueue died half-way: workspaces are not re-armed
         self.use_graph = use_graph
         self.two_streams = bool(two_streams)
         # dense() fused into the last conv's epilogue (lcf_indice_conv_fwd_dense)
@@ -258,8 +266,9 @@ class FrameEngine:
         at the END of its rulebook branch, where the fills overlap the convolutions instead of
         sitting in front of the voxelizer and of every rulebook."""
         L = self.L
+        cx = self.ctx.handle
         check(L.lcf_voxelize_workspace_reset(self.vox_ws.data_ptr(), self.vox_ws.numel(),
-                                             self.max_points, self.T, st))
+                                             self.max_points, self.T, st, cx))
         done = set()
         for l in self.layers:
             o = l.rb_owner
@@ -268,11 +277,11 @@ class FrameEngine:
             done.add(id(o))
             if o.subm:
                 check(L.lcf_rulebook_subm_workspace_reset(o.ws.data_ptr(), o.ws.numel(),
-                                                          o.k_in_cap, st))
+                                                          o.k_in_cap, st, cx))
             else:
                 check(L.lcf_rulebook_conv_workspace_reset(o.ws.data_ptr(), o.ws.numel(),
                                                           o.k_in_cap, i3(o.ksize), i3(o.stride),
-                                                          st))
+                                                          st, cx))
 
     # ------------------------------------------------------------------ one frame, enqueued
     def _enqueue(self):
@@ -281,19 +290,21 @@ class FrameEngine:
         latency-bound launches) runs on a side stream beside the feature path (VFE and the convs,
         which fill the chip).  Captured into a hipGraph the cross-stream events become edges of
         the graph: two branches that join at each conv."""
-        L = self.L
-        L.lcf_set_option(_lib.OPT_WS_CLEAN, int(os.environ.get("LCF_ENGINE_WS_CLEAN", "1")))
+        self.ctx.set(_lib.OPT_WS_CLEAN, int(os.environ.get("LCF_ENGINE_WS_CLEAN", "1")))
         self.nbr_clean = os.environ.get("LCF_ENGINE_NBR_CLEAN", "1") != "0"
-        L.lcf_set_option(_lib.OPT_NBR_CLEAN, int(self.nbr_clean))
-        try:
-            self._enqueue_clean()
-        finally:
-            L.lcf_set_option(_lib.OPT_WS_CLEAN, 0)
-            L.lcf_set_option(_lib.OPT_NBR_CLEAN, 0)
-            L.lcf_set_option(_lib.OPT_CONV_ROWS_HINT, 0)
+        self.ctx.set(_lib.OPT_NBR_CLEAN, int(self.nbr_clean))
+        if self._ws_dirty:
+            # the previous enqueue raised before its re-arming fills: the tables may hold a
+            # half-built frame, and this frame's calls skip their own resets
+            self.ctx.fill_batch_flush(torch.cuda.current_stream(self.dev).cuda_stream)
+            self._reset_workspaces(torch.cuda.current_stream(self.dev).cuda_stream)
+        self._ws_dirty = True
+        self._enqueue_clean()
+        self._ws_dirty = False
 
     def _enqueue_clean(self):
         L = self.L
+        cx = self.ctx.handle
         main = torch.cuda.current_stream(self.dev)
         side = self.side if self.two_streams else main
         st, sst = main.cuda_stream, side.cuda_stream
@@ -304,21 +315,21 @@ class FrameEngine:
         if self.nbr_clean:
             # the overflow flags and the strided levels' neighbour tables (-1 = no pair) in one
             # fill launch at the head of the rulebook branch (the previous frame is complete)
-            check(L.lcf_fill_batch_begin())
+            self.ctx.fill_batch_begin()
             try:
-                check(L.lcf_fill_u32(P(self.flags), 0, self.flags.numel() * 4, sst))
+                check(L.lcf_fill_u32(P(self.flags), 0, self.flags.numel() * 4, sst, cx))
                 for l in self.layers:
                     if not l.subm:
-                        check(L.lcf_fill_u32(P(l.nbr), 0xFFFFFFFF, l.nbr.numel() * 4, sst))
+                        check(L.lcf_fill_u32(P(l.nbr), 0xFFFFFFFF, l.nbr.numel() * 4, sst, cx))
             finally:
-                check(L.lcf_fill_batch_flush(sst))
+                self.ctx.fill_batch_flush(sst)
         else:
             with torch.cuda.stream(side):
                 self.flags.zero_()
         check(L.lcf_voxelize(P(self.points), self.max_points, P(self.n_dev), F, f3(self.vs),
                              f6(self.rng), T, MV, self.cap_mode, 0, 4, P(self.voxels),
                              P(self.coors), P(self.num), P(self.vnum), P(self.vox_ws),
-                             self.vox_ws.numel(), st))
+                             self.vox_ws.numel(), st, cx))
         kd = self.vnum
         # ---- side stream: rulebook chain + clearing of the dense output
         ready = {}
@@ -336,16 +347,17 @@ class FrameEngine:
                         continue
                     check(L.lcf_rulebook_subm(P(coors), o.k_in_cap, P(kc), 1, i3(l.in_shape),
                                               i3(l.ksize), i3(l.dil), P(o.nbr), P(o.ws),
-                                              o.ws.numel(), sst))
+                                              o.ws.numel(), sst, cx))
                     built.add(id(o))
                 else:
                     geo = (1, i3(l.in_shape), i3(l.ksize), i3(l.stride), i3(l.pad), i3(l.dil))
                     check(L.lcf_rulebook_conv_discover(P(coors), l.k_in_cap, P(kc), *geo,
                                                        P(l.out_coors), l.k_out_cap, P(l.k_out),
-                                                       P(l.flag), P(l.ws), l.ws.numel(), sst))
+                                                       P(l.flag), P(l.ws), l.ws.numel(), sst,
+                                                       cx))
                     check(L.lcf_rulebook_conv_fill(P(coors), l.k_in_cap, P(kc), *geo, l.k_out_cap,
                                                    P(l.k_out), P(l.nbr), None, P(l.ws),
-                                                   l.ws.numel(), sst))
+                                                   l.ws.numel(), sst, cx))
                     coors, kc = l.out_coors, l.k_out
                 if self.two_streams:
                     e = torch.cuda.Event()
@@ -355,16 +367,16 @@ class FrameEngine:
             # as ONE fill launch at the end of the branch
             batch = os.environ.get("LCF_ENGINE_FILL_BATCH", "1") != "0"
             if batch:
-                check(L.lcf_fill_batch_begin())
+                self.ctx.fill_batch_begin()
             try:
-                check(L.lcf_fill_u32(P(self.dense), 0, self.dense.numel() * 4, sst))
+                check(L.lcf_fill_u32(P(self.dense), 0, self.dense.numel() * 4, sst, cx))
                 if self.two_streams and not batch:
                     e_dense = torch.cuda.Event()
                     e_dense.record(side)
                 self._reset_workspaces(sst)
             finally:
                 if batch:
-                    check(L.lcf_fill_batch_flush(sst))
+                    self.ctx.fill_batch_flush(sst)
             if self.two_streams:
                 e_side = torch.cuda.Event()
                 e_side.record(side)
@@ -385,7 +397,7 @@ class FrameEngine:
                     (self.p1, 2 * u1, (w2, u2, s2, h2), self.x2, self.p2, 0),
                     (self.p2, 2 * u2, (w3, u3, s3, h3), self.x3, self.feat0, 1)):
                 check(L.lcf_indice_conv_fwd(P(x_in), P(w), None, MV * T, P(self.kt), 1, cin, cout,
-                                            P(sc), P(sh), 1, P(x_out), st))
+                                            P(sc), P(sh), 1, P(x_out), st, cx))
                 check(L.lcf_vfe_pool(P(x_out), P(self.num), MV, P(kd), T, cout, None, None, mode,
                                      P(pool_out), st))
         else:
@@ -406,7 +418,7 @@ class FrameEngine:
                 lvl += 1
             # the launch is sized by the capacity; the kernel variant by the rows expected
             need = self.level_need
-            L.lcf_set_option(_lib.OPT_CONV_ROWS_HINT, int(need[lvl]) if need else 0)
+            self.ctx.set(_lib.OPT_CONV_ROWS_HINT, int(need[lvl]) if need else 0)
             if not l.subm:
                 coors, kd = l.out_coors, l.k_out
             # dense() in the epilogue of the last conv: its rows go straight to [1,C,D,H,W]
@@ -419,18 +431,18 @@ class FrameEngine:
                 check(fwd_split(
                     P(feat), P(l.wimg), P(o.nbr), k_out_cap, P(k_out_dev), l.kvol, l.cin, l.cout,
                     P(l.scale), P(l.shift), int(l.relu), P(self.dense if to_dense else l.out),
-                    P(coors) if to_dense else None, 1, i3(self.out_shape), st))
+                    P(coors) if to_dense else None, 1, i3(self.out_shape), st, cx))
             elif to_dense:
                 check(L.lcf_indice_conv_fwd_dense(
                     P(feat), P(l.wimg), P(o.nbr), k_out_cap, P(k_out_dev), l.kvol, l.cin, l.cout,
                     P(l.scale), P(l.shift), int(l.relu), P(coors), 1, i3(self.out_shape),
-                    P(self.dense), st))
+                    P(self.dense), st, cx))
             else:
                 check(L.lcf_indice_conv_fwd(P(feat), P(l.wimg), P(o.nbr), k_out_cap,
                                             P(k_out_dev), l.kvol, l.cin, l.cout, P(l.scale),
-                                            P(l.shift), int(l.relu), P(l.out), st))
+                                            P(l.shift), int(l.relu), P(l.out), st, cx))
             feat = None if to_dense else l.out
-        L.lcf_set_option(_lib.OPT_CONV_ROWS_HINT, 0)
+        self.ctx.set(_lib.OPT_CONV_ROWS_HINT, 0)
         if feat is not None:
             if self.two_streams:
                 main.wait_event(e_dense)
@@ -502,15 +514,34 @@ class FrameEngine:
             self.graph.replay()
         else:
             self._enqueue()
-        if sync:
-            if self.overflowed():
-                ks = self.counts()
-                self.margin *= 2
-                self._plan(None)  # loose capacities; a later calibrate() tightens them again
-                if self.use_graph:
-                    self._capture()
-                return self.forward(points.clone(), sync=True)
+        if sync and self.overflowed():
+            self._replan_for(points.clone())
         return self.out
+
+    def _replan_for(self, points):
+        """A frame exceeded a level capacity: measure it with the loose (worst-case bounded)
+        capacities, re-plan tight from what it needs (x margin, merged with the calibration
+        counts), re-capture, and run it again -- once; a frame that does not fit even the loose
+        capacities raises."""
+        self.graph = None
+        self._plan(None)
+        self._load(points)
+        self._enqueue()
+        if self.overflowed():
+            raise RuntimeError("FrameEngine: the frame exceeds even the loose level capacities "
+                               f"{self.level_caps} (max_voxels = {self.max_voxels})")
+        ks = self.counts()
+        need = ks if self.level_need is None else [max(a, b) for a, b in zip(self.level_need, ks)]
+        self.level_need = list(need)
+        self._plan([_round_up(self.margin * k + 2048, 1024) for k in need[1:]])
+        if self.use_graph:
+            self._capture()
+        self._load(points)
+        if self.graph is not None:
+            self.graph.replay()
+        else:
+            self._enqueue()
+        self.check()
 
     __call__ = forward
 

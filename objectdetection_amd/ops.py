@@ -52,14 +52,15 @@ def to3(v):
 # ------------------------------------------------------------------ voxelizer
 
 def voxelize(points, voxel_size, pc_range, max_points, max_voxels, cap_mode=0, n_dev=None,
-             batch_idx=None, out=None, ws=None):
+             batch_idx=None, out=None, ws=None, ctx=None):
     """points [N,F] f32 cuda -> (voxels [max_voxels,T,F], coors [max_voxels,3] zyx,
     num_points [max_voxels], voxel_num [1] i32 device).  Rows >= voxel_num are zero.
     Bit-identical to the reference's sequential loop (include/lcf.h: lcf_voxelize).
 
     ``n_dev`` ([1] int32 cuda): the number of valid points lives on the device (N is then the
     capacity).  ``batch_idx`` not None: coors come out as [max_voxels,4] (batch_idx,z,y,x).
-    ``out`` = (voxels, coors, num, voxel_num) and ``ws`` reuse caller-owned buffers."""
+    ``out`` = (voxels, coors, num, voxel_num) and ``ws`` reuse caller-owned buffers; ``ctx`` is
+    an lcf_ctx handle (``_lib.Context().handle``) carrying per-call options."""
     _need_cuda(points)
     if points.dtype != torch.float32 or points.dim() != 2:
         raise ValueError("points must be a [N,F] float32 tensor")
@@ -80,7 +81,7 @@ def voxelize(points, voxel_size, pc_range, max_points, max_voxels, cap_mode=0, n
     check(L.lcf_voxelize(_ptr(pts), n, _ptr(n_dev), f, f3(voxel_size), f6(pc_range),
                          int(max_points), int(max_voxels), int(cap_mode), int(batch_idx or 0), cs,
                          _ptr(voxels), _ptr(coors), _ptr(num), _ptr(vnum), _ptr(ws), ws.numel(),
-                         _stream()))
+                         _stream(), ctx))
     return voxels, coors, num, vnum
 
 

@@ -552,10 +552,20 @@ def test_option_values_are_validated(cuda):
     assert L.lcf_set_option(_lib.OPT_CONV_TILE, 33) != 0
     assert L.lcf_set_option(_lib.OPT_CONV_SETS, 3) != 0
     assert L.lcf_set_option(_lib.OPT_CONV_IMPL, 4) != 0
-    assert L.lcf_set_option(_lib.OPT_WS_CLEAN, 2) != 0
-    assert L.lcf_set_option(_lib.OPT_NBR_CLEAN, 2) != 0
-    assert L.lcf_set_option(_lib.OPT_NBR_CLEAN, 0) == 0
     assert L.lcf_set_option(99, 0) != 0
+    # options that change what a call assumes about its buffers exist per context only
+    assert L.lcf_set_option(_lib.OPT_WS_CLEAN, 1) != 0
+    assert L.lcf_set_option(_lib.OPT_NBR_CLEAN, 1) != 0
+    assert L.lcf_set_option(_lib.OPT_CONV_ROWS_HINT, 100) != 0
+    ctx = _lib.Context()
+    assert L.lcf_ctx_set_option(ctx.handle, _lib.OPT_WS_CLEAN, 2) != 0
+    assert L.lcf_ctx_set_option(ctx.handle, _lib.OPT_NBR_CLEAN, 2) != 0
+    assert L.lcf_ctx_set_option(ctx.handle, _lib.OPT_NBR_CLEAN, 1) == 0
+    assert L.lcf_ctx_set_option(ctx.handle, _lib.OPT_CONV_ROWS_HINT, -1) != 0
+    assert L.lcf_ctx_set_option(ctx.handle, _lib.OPT_CONV_TILE, 15) != 0
+    assert L.lcf_ctx_set_option(ctx.handle, _lib.OPT_CONV_TILE, 24) == 0
+    assert L.lcf_ctx_set_option(None, _lib.OPT_CONV_TILE, 24) != 0
+    assert L.lcf_ctx_set_option(ctx.handle, 99, 0) != 0
 
 
 @pytest.mark.parametrize("cin,cout,subm", [(32, 32, True), (64, 64, True), (32, 64, False),

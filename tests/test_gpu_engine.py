@@ -216,19 +216,25 @@ def test_load_points_copies_and_counts_in_one_launch(cuda):
 
 
 def test_batched_fills_run_as_one_launch_with_the_same_result(cuda):
-    """lcf_fill_batch_begin / _flush: recorded fills (ragged sizes, unaligned heads, more segments
-    than one plan holds) land exactly as separate lcf_fill_u32 calls would."""
+    """lcf_ctx_fill_batch_begin / _flush: fills recorded in a caller-owned context (ragged sizes,
+    unaligned heads, more segments than one plan holds) land exactly as separate lcf_fill_u32
+    calls would; fills made meanwhile WITHOUT that context (or with another one) run at once."""
     L = _lib.lib()
     st = torch.cuda.current_stream().cuda_stream
     sizes = [1, 3, 4, 5, 255, 256, 1000, 4097, 70001, 12, 7, 33, 64, 129, 100000, 2, 9, 31, 513]
     bufs = [torch.full((n + 3,), 5, dtype=torch.int32, device=cuda) for n in sizes]
-    assert L.lcf_fill_batch_begin() == 0
+    ctx, other = _lib.Context(), _lib.Context()
+    ctx.fill_batch_begin()
     for i, (b, n) in enumerate(zip(bufs, sizes)):
         off = i % 3  # unaligned starts
-        assert L.lcf_fill_u32(b[off:].data_ptr(), 1000 + i, n * 4, st) == 0
+        assert L.lcf_fill_u32(b[off:].data_ptr(), 1000 + i, n * 4, st, ctx.handle) == 0
+    bystander = torch.zeros(8, dtype=torch.int32, device=cuda)
+    assert L.lcf_fill_u32(bystander.data_ptr(), 3, 16, st) == 0               # no context
+    assert L.lcf_fill_u32(bystander[4:].data_ptr(), 4, 16, st, other.handle) == 0  # another one
     torch.cuda.synchronize()
+    assert bystander.tolist() == [3, 3, 3, 3, 4, 4, 4, 4]
     assert all(int((b != 5).sum()) == 0 for b in bufs[-3:])  # recorded, not yet run
-    assert L.lcf_fill_batch_flush(st) == 0
+    ctx.fill_batch_flush(st)
     for i, (b, n) in enumerate(zip(bufs, sizes)):
         off = i % 3
         ref = torch.full_like(b, 5)
@@ -238,3 +244,82 @@ def test_batched_fills_run_as_one_launch_with_the_same_result(cuda):
     assert L.lcf_fill_u32(bufs[0].data_ptr(), 1, 4, st) == 0
     torch.cuda.synchronize()
     assert int(bufs[0][0]) == 1
+
+
+def test_two_engines_enqueue_from_two_threads(cuda):
+    """Re-entrancy (SURVEY.md section 8b "Threading"): each engine owns its lcf_ctx, so two engines
+    -- eager enqueue, i.e. ~60 option-dependent C calls per frame each -- driven from two threads
+    at once, beside a third thread that runs plain self-resetting ops.* calls on fresh workspaces,
+    all give what they give alone."""
+    import threading
+    model = randomize_(SparseFrontEnd("M2").eval(), 0).to(cuda)
+    clouds = {0: _clouds(cuda, [11, 12, 13], 9000), 1: _clouds(cuda, [21, 22, 23], 14000)}
+    with torch.no_grad():
+        want = {t: [model([c]).clone() for c in cs] for t, cs in clouds.items()}
+        engines = {t: model.engine(calib=cs, use_graph=False) for t, cs in clouds.items()}
+        vox_ref = [ops_voxelize(c) for c in clouds[0]]
+    torch.cuda.synchronize()
+    errs, start = [], threading.Barrier(3)
+
+    def drive(t):
+        try:
+            torch.cuda.set_device(cuda)
+            s = torch.cuda.Stream(device=cuda)
+            start.wait()
+            with torch.no_grad(), torch.cuda.stream(s):
+                for rep in range(6):
+                    for c, w in zip(clouds[t], want[t]):
+                        out = engines[t].forward(c)
+                        s.synchronize()
+                        engines[t].check()
+                        err = ((out - w).abs().max() / w.abs().max()).item()
+                        assert err < 1e-5, (t, rep, err)
+        except BaseException as e:  # noqa: BLE001 - re-raised in the main thread
+            errs.append(e)
+
+    def bystander():
+        try:
+            torch.cuda.set_device(cuda)
+            s = torch.cuda.Stream(device=cuda)
+            start.wait()
+            with torch.cuda.stream(s):
+                for rep in range(12):
+                    for c, ref in zip(clouds[0], vox_ref):
+                        got = ops_voxelize(c)  # fresh torch.empty workspace: relies on the reset
+                        s.synchronize()
+                        assert all(torch.equal(a, b) for a, b in zip(got, ref))
+        except BaseException as e:  # noqa: BLE001
+            errs.append(e)
+
+    ths = [threading.Thread(target=drive, args=(0,)), threading.Thread(target=drive, args=(1,)),
+           threading.Thread(target=bystander)]
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join(timeout=110)
+    assert not any(th.is_alive() for th in ths)
+    if errs:
+        raise errs[0]
+
+
+def ops_voxelize(c):
+    from objectdetection_amd import ops
+    return ops.voxelize(c, synth.VOXEL_SIZE, synth.PC_RANGE, 5, 40000)
+
+
+def test_overflow_replan_is_bounded_and_uses_observed_counts(cuda):
+    """forward(sync=True) on a frame that exceeds the calibrated capacities: one measuring pass
+    with loose capacities, a tight re-plan from the observed counts, one re-run -- no recursion,
+    and the kernel-selection hints follow."""
+    model = randomize_(SparseFrontEnd("M2").eval(), 0).to(cuda)
+    small = _clouds(cuda, [1], 4000)
+    big = _clouds(cuda, [2], 30000)[0]
+    with torch.no_grad():
+        eng = model.engine(calib=small, margin=1.0)
+        before = list(eng.level_caps)
+        out = eng.forward(big, sync=True).clone()
+        ref = model([big])
+    assert not eng.overflowed()
+    assert all(a >= b for a, b in zip(eng.level_caps, before)) and eng.level_caps != before
+    assert eng.level_need[0] > 20000
+    assert ((out - ref).abs().max() / ref.abs().max()).item() < 1e-5

@@ -153,13 +153,16 @@ def test_ws_clean_protocol_matches_default(cuda):
         k = int(ref[3].item())
         rb_s = ops.build_rulebook(ref[1][:k].contiguous(), 1, shape, 3, 1, 0, 1, True)
         rb_c = ops.build_rulebook(ref[1][:k].contiguous(), 1, shape, 3, 2, 1, 1, False)
-        assert L.lcf_set_option(_lib.OPT_WS_CLEAN, 1) == 0
-        try:
-            got = ops.voxelize(pts, synth.VOXEL_SIZE, synth.PC_RANGE, T, MV, batch_idx=0, ws=vws)
+        ctx = _lib.Context()
+        ctx.set(_lib.OPT_WS_CLEAN, 1)  # per context: other callers keep self-resetting calls
+        cx = ctx.handle
+        if True:
+            got = ops.voxelize(pts, synth.VOXEL_SIZE, synth.PC_RANGE, T, MV, batch_idx=0, ws=vws,
+                               ctx=cx)
             kd = got[3]
             nbr = torch.empty((MV, 27), dtype=torch.int32, device=cuda)
             check(L.lcf_rulebook_subm(P(got[1]), MV, P(kd), 1, i3(shape), i3(ks), i3(one), P(nbr),
-                                      P(sws), sws.numel(), st))
+                                      P(sws), sws.numel(), st, cx))
             cap = rb_c.k_out + 100
             oc = torch.empty((cap, 4), dtype=torch.int32, device=cuda)
             ko = torch.zeros(1, dtype=torch.int32, device=cuda)
@@ -167,11 +170,9 @@ def test_ws_clean_protocol_matches_default(cuda):
             onbr = torch.empty((cap, 27), dtype=torch.int32, device=cuda)
             geo = (1, i3(shape), i3(ks), i3(two), i3(one), i3(one))
             check(L.lcf_rulebook_conv_discover(P(got[1]), MV, P(kd), *geo, P(oc), cap, P(ko),
-                                               P(flag), P(cws), cws.numel(), st))
+                                               P(flag), P(cws), cws.numel(), st, cx))
             check(L.lcf_rulebook_conv_fill(P(got[1]), MV, P(kd), *geo, cap, P(ko), P(onbr), None,
-                                           P(cws), cws.numel(), st))
-        finally:
-            L.lcf_set_option(_lib.OPT_WS_CLEAN, 0)
+                                           P(cws), cws.numel(), st, cx))
         reset()  # re-arm for the next frame
         for a, b in zip(got, ref):
             assert torch.equal(a, b)

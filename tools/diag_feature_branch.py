@@ -24,13 +24,14 @@ class FeatureOnly(FrameEngine):
         if not getattr(self, "feature_only", False):
             return super()._enqueue_clean()
         L = self.L
+        cx = self.ctx.handle
         st = torch.cuda.current_stream(self.dev).cuda_stream
         P = lambda t: None if t is None else t.data_ptr()
         MV, T, F = self.max_voxels, self.T, self.F
         check(L.lcf_voxelize(P(self.points), self.max_points, P(self.n_dev), F, f3(self.vs),
                              f6(self.rng), T, MV, self.cap_mode, 0, 4, P(self.voxels),
                              P(self.coors), P(self.num), P(self.vnum), P(self.vox_ws),
-                             self.vox_ws.numel(), st))
+                             self.vox_ws.numel(), st, cx))
         kd = self.vnum
         check(L.lcf_fill_u32(P(self.dense), 0, self.dense.numel() * 4, st))
         (w1, c0, u1, s1, h1), (w2, _, u2, s2, h2), (w3, _, u3, s3, h3) = self.lin
@@ -46,22 +47,22 @@ class FeatureOnly(FrameEngine):
                 k_cap, k_dev = l.k_out_cap, l.k_out
                 lvl += 1
                 coors, kd = l.out_coors, l.k_out
-            L.lcf_set_option(_lib.OPT_CONV_ROWS_HINT, int(self.level_need[lvl]))
+            self.ctx.set(_lib.OPT_CONV_ROWS_HINT, int(self.level_need[lvl]))
             last = l is self.layers[-1]
             if l.x3:
                 fn = L.lcf_indice_conv_fwd_bf16x8 if l.planes == 3 else L.lcf_indice_conv_fwd_bf16x3
                 check(fn(P(feat), P(l.wimg), P(o.nbr), k_cap, P(k_dev), l.kvol, l.cin, l.cout,
                          P(l.scale), P(l.shift), int(l.relu), P(self.dense if last else l.out),
-                         P(coors) if last else None, 1, i3(self.out_shape), st))
+                         P(coors) if last else None, 1, i3(self.out_shape), st, cx))
             elif last:
                 check(L.lcf_indice_conv_fwd_dense(P(feat), P(l.wimg), P(o.nbr), k_cap, P(k_dev),
                                                   l.kvol, l.cin, l.cout, P(l.scale), P(l.shift),
                                                   int(l.relu), P(coors), 1, i3(self.out_shape),
-                                                  P(self.dense), st))
+                                                  P(self.dense), st, cx))
             else:
                 check(L.lcf_indice_conv_fwd(P(feat), P(l.wimg), P(o.nbr), k_cap, P(k_dev), l.kvol,
                                             l.cin, l.cout, P(l.scale), P(l.shift), int(l.relu),
-                                            P(l.out), st))
+                                            P(l.out), st, cx))
             feat = l.out
         check(L.lcf_voxelize_workspace_reset(self.vox_ws.data_ptr(), self.vox_ws.numel(),
                                              self.max_points, self.T, st))
