@@ -191,6 +191,45 @@ int lcf_rulebook_conv_fill(const int *coors, int k_in, const int *k_in_dev, int 
                            int *out_nbr, int *in_nbr, void *ws, size_t ws_bytes, void *stream,
                            lcf_ctx *ctx);
 
+/* All rulebooks of a SparseSequential in ONE call (the eight get_indice_pairs calls that
+ * SparseConvolution.forward makes for second/pytorch/models/middle.py:145-192: four submanifold
+ * keys + four strided convs), enqueued as few fused launches and without a host synchronisation.
+ * Same canonical result as lcf_rulebook_subm / lcf_rulebook_conv_* (out_nbr tables, out_coors in
+ * CPU-discovery order, device-side counts); builds out_nbr only (inference).
+ *
+ * `levels` (HOST array) lists the convs in network order.  A submanifold level (subm = 1) builds
+ * out_nbr [rows_cap, kvol] over the coordinates the walk currently stands on (rows_cap = k for
+ * the input level, the producing strided level's cap_out after one); a strided level produces the
+ * next coordinates: out_coors [cap_out,4], k_out [1] (clamped to cap_out), overflow [1] (written
+ * 0 or 1 on every call: the caller does not clear it), out_nbr [cap_out, kvol], and needs a
+ * workspace of lcf_rulebook_chain_workspace_bytes(k_in_cap, ksize, stride, cap_out) bytes, where
+ * k_in_cap is the row capacity of the level it reads.  Its output hash table is sized by cap_out:
+ * cap_out below the real number of outputs is reported through `overflow`, never a fault.
+ * ready_event (a hipEvent_t, or NULL) is recorded on `stream` as soon as the level's out_nbr is
+ * complete, so that a consumer on another stream can start before the whole chain is done.
+ * ws0: lcf_rulebook_subm_workspace_bytes(k) bytes (coordinate table of the input level).
+ * LCF_OPT_WS_CLEAN in ctx: the caller guarantees that lcf_rulebook_chain_reset has run on these
+ * workspaces since their last use (otherwise the call resets them first). */
+typedef struct lcf_rb_level {
+    int subm;
+    int ksize[3], stride[3], pad[3], dil[3]; /* z, y, x; stride / pad ignored for subm */
+    int *out_nbr;
+    int *out_coors; /* strided levels only, from here on */
+    int cap_out;
+    int *k_out;
+    int *overflow;
+    void *ws;
+    size_t ws_bytes;
+    void *ready_event;
+} lcf_rb_level;
+size_t lcf_rulebook_chain_workspace_bytes(int k_in_cap, const int ksize[3], const int stride[3],
+                                          int cap_out);
+int lcf_rulebook_chain_reset(const lcf_rb_level *levels, int n, int k, void *ws0, size_t ws0_bytes,
+                             void *stream, lcf_ctx *ctx);
+int lcf_rulebook_chain(const int *coors, int k, const int *k_dev, int batch, const int shape[3],
+                       const lcf_rb_level *levels, int n, void *ws0, size_t ws0_bytes,
+                       void *stream, lcf_ctx *ctx);
+
 /* mirror a submanifold table: in_nbr[j][o] = out_nbr[j][kvol-1-o] */
 int lcf_rulebook_mirror(const int *nbr, int k, int kvol, int *mirrored, void *stream);
 

@@ -14,6 +14,14 @@ _I3 = ctypes.c_int * 3
 _F3 = ctypes.c_float * 3
 _F6 = ctypes.c_float * 6
 
+class RbLevel(ctypes.Structure):
+    """lcf_rb_level (include/lcf.h)."""
+    _fields_ = [("subm", c_int), ("ksize", _I3), ("stride", _I3), ("pad", _I3), ("dil", _I3),
+                ("out_nbr", c_void_p), ("out_coors", c_void_p), ("cap_out", c_int),
+                ("k_out", c_void_p), ("overflow", c_void_p), ("ws", c_void_p),
+                ("ws_bytes", c_size_t), ("ready_event", c_void_p)]
+
+
 # every symbol include/lcf.h declares: (restype, argtypes)
 _PI3 = ctypes.POINTER(ctypes.c_int)
 _PF = ctypes.POINTER(ctypes.c_float)
@@ -52,6 +60,12 @@ SYMBOLS = {
     "lcf_rulebook_conv_fill": (c_int, [c_void_p, c_int, c_void_p, c_int, _PI3, _PI3, _PI3, _PI3,
                                        _PI3, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                        c_size_t, c_void_p, c_void_p]),
+    "lcf_rulebook_chain_workspace_bytes": (c_size_t, [c_int, _PI3, _PI3, c_int]),
+    "lcf_rulebook_chain_reset": (c_int, [ctypes.POINTER(RbLevel), c_int, c_int, c_void_p,
+                                         c_size_t, c_void_p, c_void_p]),
+    "lcf_rulebook_chain": (c_int, [c_void_p, c_int, c_void_p, c_int, _PI3,
+                                   ctypes.POINTER(RbLevel), c_int, c_void_p, c_size_t, c_void_p,
+                                   c_void_p]),
     "lcf_rulebook_mirror": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "lcf_rulebook_pairs_workspace_bytes": (c_size_t, [c_int, c_int]),
     "lcf_rulebook_pairs": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p,
@@ -125,7 +139,8 @@ CTX_LAST = {"lcf_voxelize", "lcf_voxelize_workspace_reset", "lcf_rulebook_subm",
             "lcf_rulebook_subm_workspace_reset", "lcf_rulebook_conv_workspace_reset",
             "lcf_rulebook_conv_discover", "lcf_rulebook_conv_fill", "lcf_indice_conv_fwd",
             "lcf_indice_conv_fwd_bf16", "lcf_indice_conv_fwd_bf16x3",
-            "lcf_indice_conv_fwd_bf16x8", "lcf_indice_conv_fwd_dense", "lcf_fill_u32"}
+            "lcf_indice_conv_fwd_bf16x8", "lcf_indice_conv_fwd_dense", "lcf_fill_u32",
+            "lcf_rulebook_chain", "lcf_rulebook_chain_reset"}
 
 
 class _Lib:

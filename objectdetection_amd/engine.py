@@ -201,7 +201,6 @@ class FrameEngine:
         self.num, self.vnum = E(MV, dtype=i32), torch.zeros(1, dtype=i32, device=dev)
         self.vox_ws = E(max(L.lcf_voxelize_workspace_bytes(self.max_points, T), 256),
                         dtype=torch.uint8)
-        self.flags = torch.zeros(max(self.n_strided, 1), dtype=i32, device=dev)
         self.vfe_fused = False
         if self.vfe_kind == "vfe":
             (_, c0, u1, _, _), (_, _, u2, _, _), (_, _, u3, _, _) = self.lin
@@ -219,11 +218,10 @@ class FrameEngine:
             self.feat0 = E(MV, u3)
         else:
             self.feat0 = E(MV, self.layers[0].cin)
-        # middle: level = (coors, count scalar, capacity); rulebooks per key / per strided conv
-        cap = MV
-        si = 0
-        self.level_caps = [MV]
-        keys = {}
+        # middle: all rulebooks of the stack come from ONE lcf_rulebook_chain call (one level per
+        # indice_key / per strided conv); capacities: MV rows at the input level, then each
+        # strided conv's output capacity
+        specs, cap, keys = [], MV, {}
         for l in self.layers:
             l.k_in_cap = cap
             if l.subm:
@@ -231,8 +229,8 @@ class FrameEngine:
                     l.rb_owner = keys[l.key]
                 else:
                     l.rb_owner = l
-                    l.nbr = E(cap, l.kvol, dtype=i32)
-                    l.ws = E(max(L.lcf_rulebook_subm_workspace_bytes(cap), 256), dtype=torch.uint8)
+                    l.level = len(specs)
+                    specs.append(dict(subm=True, ksize=l.ksize, dilation=l.dil))
                     if l.key is not None:
                         keys[l.key] = l
                 l.k_out_cap = cap
@@ -240,25 +238,43 @@ class FrameEngine:
                 worst = L.lcf_rulebook_conv_max_out(cap, i3(l.ksize), i3(l.stride))
                 cells = l.out_shape[0] * l.out_shape[1] * l.out_shape[2]
                 loose = min(worst, cells, 8 * MV)
+                si = sum(1 for sp in specs if not sp["subm"])
                 l.k_out_cap = loose if caps is None else min(int(caps[si]), min(worst, cells))
                 l.k_out_cap = max(l.k_out_cap, 64)
-                l.flag = self.flags[si:si + 1]
-                si += 1
-                l.out_coors = E(l.k_out_cap, 4, dtype=i32)
-                l.k_out = torch.zeros(1, dtype=i32, device=dev)
-                l.nbr = E(l.k_out_cap, l.kvol, dtype=i32)
-                l.ws = E(max(L.lcf_rulebook_conv_workspace_bytes(cap, i3(l.ksize), i3(l.stride)),
-                             256), dtype=torch.uint8)
                 l.rb_owner = l
+                l.level = len(specs)
+                specs.append(dict(subm=False, ksize=l.ksize, stride=l.stride, padding=l.pad,
+                                  dilation=l.dil))
                 cap = l.k_out_cap
-                self.level_caps.append(cap)
             l.out = E(l.k_out_cap, l.cout)
+        self.chain = ops.RulebookChain(
+            specs, MV, 1, self.sparse_shape, device=dev,
+            caps=[l.k_out_cap for l in self.layers if not l.subm])
+        self.flags = self.chain.flags
+        self.level_caps = [MV]
+        for l in self.layers:
+            if l.rb_owner is l:
+                l.nbr = self.chain.out_nbr[l.level]
+                if not l.subm:
+                    l.out_coors = self.chain.out_coors[l.level]
+                    l.k_out = self.chain.k_out[l.level]
+                    assert l.out_coors.shape[0] == l.k_out_cap
+                    self.level_caps.append(l.k_out_cap)
+        # one event per rulebook: recorded by the chain as soon as that table is complete (the
+        # handles must exist before the call: record once here)
+        self.rb_events = []
+        for i in range(self.chain.n):
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(dev))
+            self.chain.set_event(i, ev)
+            self.rb_events.append(ev)
         C = self.layers[-1].cout
         D, H, W = self.out_shape
         self.dense = E(1, C, D, H, W)
         self.out = self.dense.view(1, C * D, H, W)
         self.graph = None
         self._reset_workspaces(torch.cuda.current_stream(dev).cuda_stream)
+        self._ws_dirty = False
 
     def _reset_workspaces(self, st):
         """Hash workspaces of the voxelizer and of every rulebook into their reset state.  A frame
@@ -269,19 +285,7 @@ class FrameEngine:
         cx = self.ctx.handle
         check(L.lcf_voxelize_workspace_reset(self.vox_ws.data_ptr(), self.vox_ws.numel(),
                                              self.max_points, self.T, st, cx))
-        done = set()
-        for l in self.layers:
-            o = l.rb_owner
-            if id(o) in done:
-                continue
-            done.add(id(o))
-            if o.subm:
-                check(L.lcf_rulebook_subm_workspace_reset(o.ws.data_ptr(), o.ws.numel(),
-                                                          o.k_in_cap, st, cx))
-            else:
-                check(L.lcf_rulebook_conv_workspace_reset(o.ws.data_ptr(), o.ws.numel(),
-                                                          o.k_in_cap, i3(o.ksize), i3(o.stride),
-                                                          st, cx))
+        self.chain.reset(stream=st, ctx=cx)
 
     # ------------------------------------------------------------------ one frame, enqueued
     def _enqueue(self):
@@ -291,8 +295,6 @@ class FrameEngine:
         which fill the chip).  Captured into a hipGraph the cross-stream events become edges of
         the graph: two branches that join at each conv."""
         self.ctx.set(_lib.OPT_WS_CLEAN, int(os.environ.get("LCF_ENGINE_WS_CLEAN", "1")))
-        self.nbr_clean = os.environ.get("LCF_ENGINE_NBR_CLEAN", "1") != "0"
-        self.ctx.set(_lib.OPT_NBR_CLEAN, int(self.nbr_clean))
         if self._ws_dirty:
             # the previous enqueue raised before its re-arming fills: the tables may hold a
             # half-built frame, and this frame's calls skip their own resets
@@ -310,22 +312,8 @@ class FrameEngine:
         st, sst = main.cuda_stream, side.cuda_stream
         P = lambda t: None if t is None else t.data_ptr()
         MV, T, F = self.max_voxels, self.T, self.F
-        if self.two_streams:  # overflow flags: only the rulebook branch writes them
+        if self.two_streams:  # the previous frame is complete before this one's branch starts
             side.wait_stream(main)
-        if self.nbr_clean:
-            # the overflow flags and the strided levels' neighbour tables (-1 = no pair) in one
-            # fill launch at the head of the rulebook branch (the previous frame is complete)
-            self.ctx.fill_batch_begin()
-            try:
-                check(L.lcf_fill_u32(P(self.flags), 0, self.flags.numel() * 4, sst, cx))
-                for l in self.layers:
-                    if not l.subm:
-                        check(L.lcf_fill_u32(P(l.nbr), 0xFFFFFFFF, l.nbr.numel() * 4, sst, cx))
-            finally:
-                self.ctx.fill_batch_flush(sst)
-        else:
-            with torch.cuda.stream(side):
-                self.flags.zero_()
         check(L.lcf_voxelize(P(self.points), self.max_points, P(self.n_dev), F, f3(self.vs),
                              f6(self.rng), T, MV, self.cap_mode, 0, 4, P(self.voxels),
                              P(self.coors), P(self.num), P(self.vnum), P(self.vox_ws),
@@ -338,33 +326,14 @@ class FrameEngine:
             ev.record(main)
             side.wait_event(ev)
         with torch.cuda.stream(side):
-            coors, kc = self.coors, kd
-            built = set()
-            for l in self.layers:
-                o = l.rb_owner
-                if l.subm:
-                    if id(o) in built:
-                        continue
-                    check(L.lcf_rulebook_subm(P(coors), o.k_in_cap, P(kc), 1, i3(l.in_shape),
-                                              i3(l.ksize), i3(l.dil), P(o.nbr), P(o.ws),
-                                              o.ws.numel(), sst, cx))
-                    built.add(id(o))
-                else:
-                    geo = (1, i3(l.in_shape), i3(l.ksize), i3(l.stride), i3(l.pad), i3(l.dil))
-                    check(L.lcf_rulebook_conv_discover(P(coors), l.k_in_cap, P(kc), *geo,
-                                                       P(l.out_coors), l.k_out_cap, P(l.k_out),
-                                                       P(l.flag), P(l.ws), l.ws.numel(), sst,
-                                                       cx))
-                    check(L.lcf_rulebook_conv_fill(P(coors), l.k_in_cap, P(kc), *geo, l.k_out_cap,
-                                                   P(l.k_out), P(l.nbr), None, P(l.ws),
-                                                   l.ws.numel(), sst, cx))
-                    coors, kc = l.out_coors, l.k_out
-                if self.two_streams:
-                    e = torch.cuda.Event()
-                    e.record(side)
-                    ready[id(o)] = e
-            # the dense clear and the re-arming of the ten hash workspaces (for the next frame)
-            # as ONE fill launch at the end of the branch
+            # every rulebook of the stack: one call, ~14 fused launches, an event per table
+            self.chain.run(self.coors, k_dev=kd, stream=sst, ctx=cx)
+            if self.two_streams:
+                for l in self.layers:
+                    if l.rb_owner is l:
+                        ready[id(l)] = self.rb_events[l.level]
+            # the dense clear and the re-arming of the hash workspaces (for the next frame) as ONE
+            # fill launch at the end of the branch
             batch = os.environ.get("LCF_ENGINE_FILL_BATCH", "1") != "0"
             if batch:
                 self.ctx.fill_batch_begin()

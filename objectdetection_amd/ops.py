@@ -206,6 +206,84 @@ def build_rulebook(indices, batch_size, spatial_shape, ksize, stride, padding, d
                     dilation, out_nbr, in_nbr)
 
 
+class RulebookChain:
+    """All rulebooks of a SparseSequential in one call (include/lcf.h: lcf_rulebook_chain), with
+    caller-owned buffers sized once for capacities -- what FrameEngine replays per frame.
+
+    specs: the convs in network order, dicts with subm, ksize, stride, padding, dilation.
+    caps: output-row capacity of every strided conv (None = its worst case).  After ``run`` each
+    level i holds ``out_nbr[i]`` [rows_cap, kvol]; strided levels also ``out_coors[i]``,
+    ``k_out[i]`` (device count) and their entry of ``flags`` (overflow)."""
+
+    def __init__(self, specs, k_cap, batch_size, spatial_shape, caps=None, device=None):
+        L = _lib.lib()
+        dev = torch.device("cuda", torch.cuda.current_device()) if device is None else device
+        self.L, self.dev = L, dev
+        self.k_cap, self.batch, self.shape = int(k_cap), int(batch_size), to3(list(spatial_shape))
+        self.n = len(specs)
+        self.levels = (_lib.RbLevel * self.n)()
+        self.out_nbr, self.out_coors, self.k_out, self.ws = {}, {}, {}, {}
+        self.rows_cap, self.kvol, self.out_shape = [], [], []
+        self.strided = [i for i, sp in enumerate(specs) if not sp["subm"]]
+        self.flags = torch.zeros(max(len(self.strided), 1), dtype=torch.int32, device=dev)
+        cap, shape, si = self.k_cap, list(self.shape), 0
+        i32 = torch.int32
+        for i, sp in enumerate(specs):
+            lv = self.levels[i]
+            ks, dl = to3(sp["ksize"]), to3(sp.get("dilation", 1))
+            st, pd = to3(sp.get("stride", 1)), to3(sp.get("padding", 0))
+            lv.subm = int(bool(sp["subm"]))
+            lv.ksize, lv.stride, lv.pad, lv.dil = i3(ks), i3(st), i3(pd), i3(dl)
+            kvol = _prod(ks)
+            self.kvol.append(kvol)
+            if sp["subm"]:
+                self.out_nbr[i] = torch.empty((max(cap, 1), kvol), dtype=i32, device=dev)
+            else:
+                worst = L.lcf_rulebook_conv_max_out(cap, i3(ks), i3(st))
+                shape = conv_out_shape(shape, ks, st, pd, dl)
+                cells = self.batch * shape[0] * shape[1] * shape[2]
+                co = min(worst, cells) if caps is None else min(int(caps[si]), worst, cells)
+                co = max(co, 64)
+                nbytes = L.lcf_rulebook_chain_workspace_bytes(cap, i3(ks), i3(st), co)
+                if nbytes == 0:
+                    raise RuntimeError("rulebook chain: level too large for 32-bit stamps")
+                self.ws[i] = _ws(nbytes, dev)
+                self.out_coors[i] = torch.empty((co, 4), dtype=i32, device=dev)
+                self.k_out[i] = torch.zeros(1, dtype=i32, device=dev)
+                self.out_nbr[i] = torch.empty((co, kvol), dtype=i32, device=dev)
+                lv.out_coors = self.out_coors[i].data_ptr()
+                lv.cap_out = co
+                lv.k_out = self.k_out[i].data_ptr()
+                lv.overflow = self.flags[si:si + 1].data_ptr()
+                lv.ws, lv.ws_bytes = self.ws[i].data_ptr(), self.ws[i].numel()
+                si += 1
+                cap = co
+            lv.out_nbr = self.out_nbr[i].data_ptr()
+            self.rows_cap.append(cap)
+            self.out_shape.append(list(shape))
+        self.ws0 = _ws(L.lcf_rulebook_subm_workspace_bytes(self.k_cap), dev)
+
+    def set_event(self, i, event):
+        """Record ``event`` (a torch.cuda.Event that has been recorded once, so that its handle
+        exists) when level i's table is complete."""
+        self.levels[i].ready_event = event.cuda_event
+
+    def reset(self, stream=None, ctx=None):
+        check(self.L.lcf_rulebook_chain_reset(self.levels, self.n, self.k_cap, _ptr(self.ws0),
+                                              self.ws0.numel(),
+                                              _stream() if stream is None else stream, ctx))
+
+    def run(self, indices, k_dev=None, stream=None, ctx=None):
+        """indices [k_cap (or fewer, without k_dev), 4] i32 cuda."""
+        k = self.k_cap if k_dev is not None else int(indices.shape[0])
+        if k > self.k_cap:
+            raise ValueError("rulebook chain: more rows than the planned capacity")
+        check(self.L.lcf_rulebook_chain(_ptr(indices), k, _ptr(k_dev), self.batch,
+                                        i3(self.shape), self.levels, self.n, _ptr(self.ws0),
+                                        self.ws0.numel(),
+                                        _stream() if stream is None else stream, ctx))
+
+
 # ------------------------------------------------------------------ indice_conv
 
 def weight_image(weight, transpose=False):

@@ -1,0 +1,156 @@
+"""GPU parity: lcf_rulebook_chain (all rulebooks of a SparseSequential in fused launches) against
+the oracle's get_indice_pairs restatement -- canonical pairs and output coordinates bit-exact --
+and against the one-rulebook-per-call entry points."""
+import numpy as np
+import pytest
+import torch
+
+from objectdetection_amd import ops, synth
+
+pytestmark = pytest.mark.gpu
+
+FHD = [  # second/pytorch/models/middle.py:145-192 (SpMiddleFHD): one entry per rulebook
+    dict(subm=True, ksize=3),
+    dict(subm=False, ksize=3, stride=2, padding=1),
+    dict(subm=True, ksize=3),
+    dict(subm=False, ksize=3, stride=2, padding=1),
+    dict(subm=True, ksize=3),
+    dict(subm=False, ksize=3, stride=2, padding=[0, 1, 1]),
+    dict(subm=True, ksize=3),
+    dict(subm=False, ksize=[3, 1, 1], stride=[2, 1, 1]),
+]
+
+
+def pairs_from_out_nbr(out_nbr, k_in):
+    """out_nbr [k_out, kvol] -> spconv's canonical (pairs [2,kvol,k_in] -1 padded, pair_num):
+    pairs of one offset in ascending input row order."""
+    k_out, kvol = out_nbr.shape
+    pairs = -np.ones((2, kvol, k_in), np.int32)
+    num = np.zeros(kvol, np.int32)
+    for o in range(kvol):
+        outs = np.nonzero(out_nbr[:, o] >= 0)[0]
+        ins = out_nbr[outs, o]
+        order = np.argsort(ins, kind="stable")
+        num[o] = len(outs)
+        pairs[0, o, :len(outs)] = ins[order]
+        pairs[1, o, :len(outs)] = outs[order]
+    return pairs, num
+
+
+def check_chain_against_oracle(oracle, coors, batch, shape, specs, caps=None):
+    dev = coors.device
+    chain = ops.RulebookChain(specs, coors.shape[0], batch, shape, caps=caps, device=dev)
+    chain.run(coors.contiguous())
+    torch.cuda.synchronize()
+    assert int(chain.flags.sum()) == 0
+    c_np, sh = coors.cpu().numpy(), list(shape)
+    for i, sp in enumerate(specs):
+        k_in = c_np.shape[0]
+        if sp["subm"]:
+            ep, en = oracle.rulebook_subm(c_np, batch, sh, sp["ksize"], sp.get("dilation", 1))
+            got = chain.out_nbr[i][:k_in].cpu().numpy()
+        else:
+            eo, ep, en, sh = oracle.rulebook_conv(c_np, batch, sh, sp["ksize"], sp["stride"],
+                                                  sp.get("padding", 0), sp.get("dilation", 1))
+            k_out = int(chain.k_out[i].item())
+            assert k_out == eo.shape[0], (i, k_out, eo.shape[0])
+            assert np.array_equal(chain.out_coors[i][:k_out].cpu().numpy(), eo), i
+            got = chain.out_nbr[i][:k_out].cpu().numpy()
+            c_np = eo
+        gp, gn = pairs_from_out_nbr(got, k_in)
+        assert np.array_equal(gn, en), (i, gn, en)
+        for o in range(len(en)):
+            assert np.array_equal(gp[:, o, :en[o]], ep[:, o, :en[o]]), (i, o)
+        assert chain.out_shape[i] == list(sh)
+    return chain
+
+
+@pytest.mark.parametrize("seed,n", [(0, 20000), (1, 6000)])
+def test_fhd_chain_matches_oracle(oracle, cuda, seed, n):
+    pts = torch.from_numpy(synth.vkitti_frame(seed, n)).to(cuda)
+    _, coors, _, vnum = ops.voxelize(pts, synth.VOXEL_SIZE, synth.PC_RANGE, 5, 40000, batch_idx=0)
+    coors = coors[:int(vnum.item())]
+    check_chain_against_oracle(oracle, coors, 1, [41, 1600, 1408], FHD)
+
+
+def test_fhd_chain_batch2_with_device_counts_and_tight_caps(oracle, cuda):
+    """Two scenes, row counts on the device, capacities just above what the levels need, run
+    twice on the same workspaces (re-armed by the call itself)."""
+    cs = []
+    for b, (seed, n) in enumerate([(3, 9000), (4, 14000)]):
+        pts = torch.from_numpy(synth.vkitti_frame(seed, n)).to(cuda)
+        _, c, _, vnum = ops.voxelize(pts, synth.VOXEL_SIZE, synth.PC_RANGE, 5, 40000, batch_idx=b)
+        cs.append(c[:int(vnum.item())])
+    coors = torch.cat(cs).contiguous()
+    loose = check_chain_against_oracle(oracle, coors, 2, [41, 1600, 1408], FHD)
+    need = [int(loose.k_out[i].item()) for i in loose.strided]
+    caps = [k + 7 for k in need]
+    k = coors.shape[0]
+    cap_rows = k + 1000
+    padded = torch.cat([coors, torch.full((1000, 4), -5, dtype=torch.int32, device=cuda)])
+    k_dev = torch.tensor([k], dtype=torch.int32, device=cuda)
+    chain = ops.RulebookChain(FHD, cap_rows, 2, [41, 1600, 1408], caps=caps, device=cuda)
+    for rep in range(2):
+        chain.run(padded, k_dev=k_dev)
+        torch.cuda.synchronize()
+        assert int(chain.flags.sum()) == 0
+        rows = k
+        for i in range(len(FHD)):
+            if not FHD[i]["subm"]:
+                rows = int(chain.k_out[i].item())
+                assert rows == int(loose.k_out[i].item())
+                assert torch.equal(chain.out_coors[i][:rows], loose.out_coors[i][:rows])
+            assert torch.equal(chain.out_nbr[i][:rows], loose.out_nbr[i][:rows]), (rep, i)
+
+
+def test_chain_reports_overflow_instead_of_faulting(cuda):
+    pts = torch.from_numpy(synth.vkitti_frame(5, 20000)).to(cuda)
+    _, coors, _, vnum = ops.voxelize(pts, synth.VOXEL_SIZE, synth.PC_RANGE, 5, 40000, batch_idx=0)
+    coors = coors[:int(vnum.item())].contiguous()
+    for caps in ([100, 100000, 100000, 100000], [100000, 64, 100000, 100000],
+                 [100000, 100000, 100000, 3000]):
+        chain = ops.RulebookChain(FHD, coors.shape[0], 1, [41, 1600, 1408], caps=caps,
+                                  device=cuda)
+        chain.run(coors)
+        torch.cuda.synchronize()
+        flags = chain.flags.tolist()
+        first = [c < 100000 for c in caps].index(True)
+        assert flags[first] == 1 and sum(flags[:first]) == 0
+        for i in chain.strided:
+            assert 0 <= int(chain.k_out[i].item()) <= chain.out_coors[i].shape[0]
+    # and the same object, re-run with room, is clean again (overflow is rewritten every call)
+    chain = ops.RulebookChain(FHD, coors.shape[0], 1, [41, 1600, 1408], device=cuda)
+    chain.run(coors)
+    torch.cuda.synchronize()
+    assert chain.flags.tolist() == [0, 0, 0, 0]
+
+
+@pytest.mark.parametrize("specs,shape", [
+    # classic grid (SparseMiddleExtractor, middle.py:62-93): subm, (3,1,1)/(2,1,1), 2 x subm, ...
+    ([dict(subm=True, ksize=3), dict(subm=False, ksize=[3, 1, 1], stride=[2, 1, 1]),
+      dict(subm=True, ksize=3), dict(subm=False, ksize=[3, 1, 1], stride=[2, 1, 1])],
+     [11, 400, 352]),
+    # a strided conv first, two strided convs in a row, dilation, two subm keys on one level
+    ([dict(subm=False, ksize=3, stride=2, padding=1), dict(subm=False, ksize=2, stride=2),
+      dict(subm=True, ksize=3, dilation=2), dict(subm=True, ksize=[1, 3, 3]),
+      dict(subm=True, ksize=3), dict(subm=True, ksize=[3, 1, 1]), dict(subm=True, ksize=1)],
+     [24, 96, 80]),
+    ([dict(subm=False, ksize=3, stride=1, padding=1, dilation=2), dict(subm=True, ksize=3)],
+     [12, 40, 36]),
+    ([dict(subm=True, ksize=3)], [9, 30, 30]),
+])
+def test_other_chains_match_oracle(oracle, cuda, specs, shape):
+    rng = np.random.default_rng(7)
+    cells = rng.choice(shape[0] * shape[1] * shape[2], size=900, replace=False)
+    c = np.stack([np.zeros_like(cells), cells // (shape[1] * shape[2]),
+                  (cells // shape[2]) % shape[1], cells % shape[2]], 1).astype(np.int32)
+    check_chain_against_oracle(oracle, torch.from_numpy(c).to(cuda), 1, shape, specs)
+
+
+def test_chain_empty_input(cuda):
+    chain = ops.RulebookChain(FHD, 128, 1, [41, 1600, 1408], device=cuda)
+    k_dev = torch.zeros(1, dtype=torch.int32, device=cuda)
+    chain.run(torch.zeros((128, 4), dtype=torch.int32, device=cuda), k_dev=k_dev)
+    torch.cuda.synchronize()
+    assert all(int(chain.k_out[i].item()) == 0 for i in chain.strided)
+    assert chain.flags.tolist() == [0, 0, 0, 0]
