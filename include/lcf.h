@@ -74,6 +74,8 @@ int lcf_version(void);
  *   calls leave it dirty.  0 = every call resets its workspace itself.
  * LCF_OPT_NBR_CLEAN: 1 = lcf_rulebook_conv_fill skips filling out_nbr / in_nbr with -1: the
  *   caller has done it (e.g. all tables of a frame in one batched fill).
+ * LCF_OPT_RB_UNFUSED: 1 = lcf_rulebook_chain launches every step by itself instead of sharing
+ *   launches (profiling: each step then shows up under its own kernel name).  Same results.
  *
  * lcf_set_option() sets process-wide DEFAULTS of the four kernel-selection knobs only (SPLIT,
  * IMPL, TILE, SETS; what a context leaves at 0 takes the default) -- for benchmarks and tests that
@@ -86,6 +88,7 @@ int lcf_version(void);
 #define LCF_OPT_CONV_ROWS_HINT 4
 #define LCF_OPT_WS_CLEAN 5
 #define LCF_OPT_NBR_CLEAN 6
+#define LCF_OPT_RB_UNFUSED 7
 typedef struct lcf_ctx lcf_ctx;
 int lcf_ctx_create(lcf_ctx **out);
 void lcf_ctx_destroy(lcf_ctx *ctx);

@@ -170,6 +170,7 @@ class _Lib:
 OPT_CONV_SPLIT, OPT_CONV_IMPL, OPT_CONV_TILE, OPT_CONV_SETS, OPT_CONV_ROWS_HINT = 0, 1, 2, 3, 4
 OPT_WS_CLEAN = 5
 OPT_NBR_CLEAN = 6
+OPT_RB_UNFUSED = 7
 
 _lib = None
 

@@ -26,6 +26,7 @@ struct LcfOpts {
     int conv_split, conv_impl, conv_tile, conv_sets; // kernel selection (0 = choose)
     int rows_hint;                                   // expected rows of the next conv launches
     int ws_clean, nbr_clean;                         // caller-guaranteed buffer states
+    int rb_unfused;                                  // profiling: lcf_rulebook_chain, one role per launch
 };
 #define LCF_FILL_MAX_SEGS 16
 struct LcfFillSeg {
@@ -62,6 +63,7 @@ struct LcfCall {
             eff.rows_hint = c->o.rows_hint;
             eff.ws_clean = c->o.ws_clean;
             eff.nbr_clean = c->o.nbr_clean;
+            eff.rb_unfused = c->o.rb_unfused;
         }
         prev = t_lcf_opts;
         t_lcf_opts = &eff;

@@ -117,6 +117,10 @@ extern "C" int lcf_ctx_set_option(lcf_ctx *ctx, int option, int value)
         if (value < 0) return LCF_ERR_ARG;
         ctx->o.rows_hint = value;
         return LCF_OK;
+    case LCF_OPT_RB_UNFUSED:
+        if (value != 0 && value != 1) return LCF_ERR_ARG;
+        ctx->o.rb_unfused = value;
+        return LCF_OK;
     default:
         return opt_store(option, value, &ctx->o.conv_split, &ctx->o.conv_impl, &ctx->o.conv_tile,
                          &ctx->o.conv_sets);

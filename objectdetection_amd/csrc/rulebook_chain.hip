@@ -16,7 +16,12 @@
 //   * the output table is sized by the OUTPUT capacity (2 x cap_out slots), not by the number of
 //     candidates (2 x k_in x E): 8-16x smaller, L2-resident; a table that fills up can only do so
 //     when the level overflows, which is reported; probing is bounded.
-// Launches for SpMiddleFHD: 2 + 3 per strided level + ... = 14 (was 24 + 2 fills).
+// Launches for SpMiddleFHD: 2 + 3 per strided level = 14 (was 24 + 2 fills).
+// Measured and NOT kept (tools/bench_chain.py, per-step kernel times): several independent items
+// per thread (fewer, longer waves: every step 30-60% slower -- a frame's tables are small enough
+// that all waves are resident at once, so more waves beat more chains per wave); a relaxed
+// agent-scope load in front of the CAS (inserts 9-16 -> 11-16 us); table entries rewritten as
+// key<<32|id by the assign step so that look-ups need one load (look-ups -10%, assign +40%).
 #include "rb_common.h"
 
 #define RBC_MAX_ROLES 4
@@ -202,7 +207,10 @@ __device__ __forceinline__ void rbc_lookup(const RbcRole &R, unsigned blk)
     R.nbr[t] = res;
 }
 
-__global__ void __launch_bounds__(RB_BLOCK) rbc_kernel(const RbcLaunch L)
+// TAG only names the launch for profilers: 0 = level-0 table + first inserts, 1 = count (+ level-0
+// look-ups), 2 = assign, 3 = fill + look-ups + next inserts; 10 + kind = one role alone
+// (LCF_OPT_RB_UNFUSED, profiling).
+template <int TAG> __global__ void __launch_bounds__(RB_BLOCK) rbc_kernel(const RbcLaunch L)
 {
     __shared__ int lds[8];
     int i = 0;
@@ -290,12 +298,41 @@ static unsigned rbc_blocks(long long items)
     return nb < 1 ? 1u : (unsigned)nb;
 }
 
-static int rbc_launch(RbcLaunch &L, unsigned blocks, hipStream_t st)
+template <int TAG> static int rbc_launch_tag(const RbcLaunch &L, unsigned blocks, hipStream_t st)
 {
-    if (L.n == 0) return LCF_OK;
-    rbc_kernel<<<blocks, RB_BLOCK, 0, st>>>(L);
+    rbc_kernel<TAG><<<blocks, RB_BLOCK, 0, st>>>(L);
     LCF_CHECK_LAUNCH();
     return LCF_OK;
+}
+
+static int rbc_launch(RbcLaunch &L, unsigned blocks, hipStream_t st, int tag, bool unfused)
+{
+    if (L.n == 0) return LCF_OK;
+    if (unfused) { // profiling: every role as a launch of its own, named by its kind
+        for (int i = 0; i < L.n; ++i) {
+            RbcLaunch one{};
+            one.n = 1;
+            one.r[0] = L.r[i];
+            const unsigned nb = (i + 1 < L.n ? L.r[i + 1].blk0 : blocks) - L.r[i].blk0;
+            one.r[0].blk0 = 0;
+            int rc;
+            switch (one.r[0].kind) {
+            case RBC_INS32: rc = rbc_launch_tag<11>(one, nb, st); break;
+            case RBC_INS64: rc = rbc_launch_tag<12>(one, nb, st); break;
+            case RBC_COUNT: rc = rbc_launch_tag<13>(one, nb, st); break;
+            case RBC_ASSIGN: rc = rbc_launch_tag<14>(one, nb, st); break;
+            default: rc = rbc_launch_tag<15>(one, nb, st); break;
+            }
+            if (rc) return rc;
+        }
+        return LCF_OK;
+    }
+    switch (tag) {
+    case 0: return rbc_launch_tag<0>(L, blocks, st);
+    case 1: return rbc_launch_tag<1>(L, blocks, st);
+    case 2: return rbc_launch_tag<2>(L, blocks, st);
+    default: return rbc_launch_tag<3>(L, blocks, st);
+    }
 }
 
 // state of the level the walk stands on
@@ -348,6 +385,7 @@ extern "C" int lcf_rulebook_chain(const int *coors, int k, const int *k_dev, int
     if (k >= (1 << 25)) return LCF_ERR_RANGE;
     if (ws0_bytes < lcf_rulebook_subm_workspace_bytes(k)) return LCF_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
+    const bool unfused = ctx && ctx->o.rb_unfused;
 
     // ---- plan: geometry and workspace of every level, validated before anything is enqueued
     RbcPlanLevel plan[64];
@@ -473,7 +511,7 @@ extern "C" int lcf_rulebook_chain(const int *coors, int k, const int *k_dev, int
         R.mask32 = hc0 - 1;
         blocks += rbc_blocks(k);
         if (s < n) add_ins64(L, blocks, cur, plan[s]);
-        int rc = rbc_launch(L, blocks, st);
+        int rc = rbc_launch(L, blocks, st, 0, unfused);
         if (rc) return rc;
     }
     while (true) {
@@ -501,7 +539,7 @@ extern "C" int lcf_rulebook_chain(const int *coors, int k, const int *k_dev, int
                 // the fill launch)
                 while (i < s) {
                     if (L.n == RBC_MAX_ROLES) {
-                        int rc = rbc_launch(L, blocks, st);
+                        int rc = rbc_launch(L, blocks, st, 1, unfused);
                         if (rc) return rc;
                         L = RbcLaunch{};
                         blocks = 0;
@@ -510,7 +548,7 @@ extern "C" int lcf_rulebook_chain(const int *coors, int k, const int *k_dev, int
                     ++i;
                 }
             }
-            int rc = rbc_launch(L, blocks, st);
+            int rc = rbc_launch(L, blocks, st, 1, unfused);
             if (rc) return rc;
             for (int j = first_unrecorded; j < s; ++j) {
                 rc = record(j);
@@ -536,7 +574,7 @@ extern "C" int lcf_rulebook_chain(const int *coors, int k, const int *k_dev, int
             R.out_coors = lv[s].out_coors;
             R.k_out = lv[s].k_out;
             R.overflow = lv[s].overflow;
-            int rc = rbc_launch(L, (unsigned)plan[s].w.nblk, st);
+            int rc = rbc_launch(L, (unsigned)plan[s].w.nblk, st, 2, unfused);
             if (rc) return rc;
         }
         // launch X: fill of the strided level (probes the level it read), submanifold look-ups of
@@ -559,7 +597,7 @@ extern "C" int lcf_rulebook_chain(const int *coors, int k, const int *k_dev, int
                 ++j;
             }
             if (s2 < n) add_ins64(L, blocks, nxt, plan[s2]);
-            int rc = rbc_launch(L, blocks, st);
+            int rc = rbc_launch(L, blocks, st, 3, unfused);
             if (rc) return rc;
             for (int q = s; q < j; ++q) {
                 rc = record(q);
