@@ -208,8 +208,9 @@ int lcf_rulebook_conv_fill(const int *coors, int k_in, const int *k_in_dev, int 
  * workspace of lcf_rulebook_chain_workspace_bytes(k_in_cap, ksize, stride, cap_out) bytes, where
  * k_in_cap is the row capacity of the level it reads.  Its output hash table is sized by cap_out:
  * cap_out below the real number of outputs is reported through `overflow`, never a fault.
- * ready_event (a hipEvent_t, or NULL) is recorded on `stream` as soon as the level's out_nbr is
- * complete, so that a consumer on another stream can start before the whole chain is done.
+ * ready_event (a hipEvent_t, or NULL) is recorded on `stream` as soon as the level's out_nbr (and
+ * its tile plan, if `plan` is given: see lcf_conv_tile_plan) is complete, so that a consumer on
+ * another stream can start before the whole chain is done.
  * ws0: lcf_rulebook_subm_workspace_bytes(k) bytes (coordinate table of the input level).
  * LCF_OPT_WS_CLEAN in ctx: the caller guarantees that lcf_rulebook_chain_reset has run on these
  * workspaces since their last use (otherwise the call resets them first). */
@@ -224,6 +225,8 @@ typedef struct lcf_rb_level {
     void *ws;
     size_t ws_bytes;
     void *ready_event;
+    int *plan;          /* optional: lcf_conv_tile_plan of this level's out_nbr, built before */
+    int plan_tile_rows; /* ready_event is recorded (tile height lcf_conv_tile_rows(...)) */
 } lcf_rb_level;
 size_t lcf_rulebook_chain_workspace_bytes(int k_in_cap, const int ksize[3], const int stride[3],
                                           int cap_out);
@@ -319,6 +322,29 @@ int lcf_indice_conv_fwd_dense(const float *feat, const float *wimg, const int *n
                               const float *scale, const float *shift, int relu,
                               const int *out_coors, int batch, const int shape[3], float *dense,
                               void *stream, lcf_ctx *ctx);
+/* Tile plans (no counterpart in the reference: spconv re-derives its gather lists per call).
+ * The tile-compacted forward kernels start every tile by compacting its rows per kernel offset;
+ * the result depends on the neighbour table only, so it can be computed ONCE per rulebook and
+ * shared by every conv over it (the two or three SubMConv3d of one indice_key,
+ * second/pytorch/models/middle.py:146-183) and built off the critical path.
+ *   lcf_conv_tile_rows(rows): the tile height the forward picks for a launch expecting `rows`.
+ *   lcf_conv_tile_plan: plan [lcf_conv_tile_plan_ints(k, kvol, tile_rows)] int32 (16-byte
+ *     aligned) from nbr [k, kvol] (out_nbr for the forward, in_nbr for dgrad); k / k_dev as
+ *     everywhere.
+ *   lcf_indice_conv_fwd_planned: the forward over a plan instead of a table -- same kernels, same
+ *     arithmetic and summation order, bit-identical results.  math 0: fp32 MFMA
+ *     (lcf_indice_conv_fwd, or _dense when dense_coors != NULL), 1: bf16 operands (no dense
+ *     target), 2: bf16x3, 3: bf16x8; wimg is the weight image of that form.  cin, cout in
+ *     {32, 64, 128}; k_out (capacity) and tile_rows must be the ones the plan was built with. */
+size_t lcf_conv_tile_plan_ints(int k_cap, int kvol, int tile_rows);
+int lcf_conv_tile_rows(int rows);
+int lcf_conv_tile_plan(const int *nbr, int k, const int *k_dev, int kvol, int tile_rows, int *plan,
+                       void *stream);
+int lcf_indice_conv_fwd_planned(const float *feat, const void *wimg, int math, const int *plan,
+                                int tile_rows, int k_out, const int *k_out_dev, int kvol, int cin,
+                                int cout, const float *scale, const float *shift, int relu,
+                                float *out, const int *dense_coors, int batch, const int shape[3],
+                                void *stream, lcf_ctx *ctx);
 int lcf_indice_conv_wgrad(const float *feat, const float *dout, const int *in_nbr, int k_in,
                           int kvol, int cin, int cout, float *dw, void *stream);
 

@@ -19,7 +19,8 @@ class RbLevel(ctypes.Structure):
     _fields_ = [("subm", c_int), ("ksize", _I3), ("stride", _I3), ("pad", _I3), ("dil", _I3),
                 ("out_nbr", c_void_p), ("out_coors", c_void_p), ("cap_out", c_int),
                 ("k_out", c_void_p), ("overflow", c_void_p), ("ws", c_void_p),
-                ("ws_bytes", c_size_t), ("ready_event", c_void_p)]
+                ("ws_bytes", c_size_t), ("ready_event", c_void_p), ("plan", c_void_p),
+                ("plan_tile_rows", c_int)]
 
 
 # every symbol include/lcf.h declares: (restype, argtypes)
@@ -92,6 +93,13 @@ SYMBOLS = {
     "lcf_indice_conv_fwd_dense": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int,
                                           c_int, c_int, c_void_p, c_void_p, c_int, c_void_p,
                                           c_int, _PI3, c_void_p, c_void_p, c_void_p]),
+    "lcf_conv_tile_plan_ints": (c_size_t, [c_int, c_int, c_int]),
+    "lcf_conv_tile_rows": (c_int, [c_int]),
+    "lcf_conv_tile_plan": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "lcf_indice_conv_fwd_planned": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int,
+                                            c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,
+                                            c_int, c_void_p, c_void_p, c_int, _PI3, c_void_p,
+                                            c_void_p]),
     "lcf_indice_conv_wgrad": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                       c_void_p, c_void_p]),
     "lcf_linear_wgrad": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
@@ -140,7 +148,7 @@ CTX_LAST = {"lcf_voxelize", "lcf_voxelize_workspace_reset", "lcf_rulebook_subm",
             "lcf_rulebook_conv_discover", "lcf_rulebook_conv_fill", "lcf_indice_conv_fwd",
             "lcf_indice_conv_fwd_bf16", "lcf_indice_conv_fwd_bf16x3",
             "lcf_indice_conv_fwd_bf16x8", "lcf_indice_conv_fwd_dense", "lcf_fill_u32",
-            "lcf_rulebook_chain", "lcf_rulebook_chain_reset"}
+            "lcf_rulebook_chain", "lcf_rulebook_chain_reset", "lcf_indice_conv_fwd_planned"}
 
 
 class _Lib:

@@ -27,6 +27,8 @@ struct LcfOpts {
     int rows_hint;                                   // expected rows of the next conv launches
     int ws_clean, nbr_clean;                         // caller-guaranteed buffer states
     int rb_unfused;                                  // profiling: lcf_rulebook_chain, one role per launch
+    const int *plan;                                 // tile plan of the call in progress (not an option:
+    int plan_tr;                                     // set by lcf_indice_conv_fwd_planned), its tile height
 };
 #define LCF_FILL_MAX_SEGS 16
 struct LcfFillSeg {

@@ -579,6 +579,91 @@ static size_t tc_lds_bytes(int CIN, int COUT, int TR, int kvol, bool bf16 = fals
 
 #define TC_THREADS(COUT) (((COUT) / 16 >= 4 ? 4 : (COUT) / 16) * 64)
 
+// The set-up of one tile of the tile-compacted kernels: neighbour tile -> LDS, rows per offset,
+// steps (= active offsets ascending), and the gather entries of every 16-row group.  Leaves, in
+// LDS: ent [items][16] ((input row << 7) | tile row; a group's padding entries gather a valid row
+// and point at the dump row), cnt / gbase [64] per offset, soff [64] per step, *nsteps_p.
+// Used by cv_tc_kernel (per launch) and by cv_plan_kernel (once per rulebook).
+template <int NWT, int TT>
+__device__ __forceinline__ void tc_build_steps(const int *__restrict__ nbr, int row0, int tr,
+                                               int kvol, int k_out, int *nl, unsigned *ent,
+                                               int *cnt, int *gbase, int *soff, int *nsteps_p,
+                                               int DUMP)
+{
+    const int tidw = threadIdx.x;
+    const int lane = tidw & 63;
+    const int wavew = __builtin_amdgcn_readfirstlane(tidw >> 6);
+    // ---- neighbour tile -> LDS (coalesced; rows past k_out read as -1)
+    {
+        const int total = tr * kvol;
+        const long long gbase_e = (long long)row0 * kvol;
+        const long long glimit = (long long)k_out * kvol;
+        for (int e = tidw; e < total; e += TT) {
+            int v = -1;
+            if (gbase_e + e < glimit) v = nbr ? nbr[gbase_e + e] : row0 + e; // NULL: identity
+            nl[e] = v;
+        }
+    }
+    __syncthreads();
+    // ---- rows per offset.  A wave takes offsets wavew, wavew + NWT, ...: the (up to MAXO) neighbour
+    //      ids of its lane's row are read once and kept, with their ballots, for the entry pass
+    //      below (the reads are independent: one LDS round trip, not one per offset)
+    constexpr int MAXO = (LCF_MAX_KVOL + NWT - 1) / NWT;
+    int idv[MAXO];
+#pragma unroll
+    for (int i = 0; i < MAXO; ++i) {
+        const int o = wavew + i * NWT;
+        idv[i] = (o < kvol && lane < tr) ? nl[lane * kvol + o] : -1;
+    }
+#pragma unroll
+    for (int i = 0; i < MAXO; ++i) {
+        const int o = wavew + i * NWT;
+        if (o < kvol) { // wave-uniform
+            const unsigned long long m = __ballot(idv[i] >= 0);
+            if (lane == 0) cnt[o] = __popcll(m);
+        }
+    }
+    __syncthreads();
+    // ---- steps = active offsets ascending; items = their 16-row groups
+    if (wavew == 0) {
+        const int c = lane < kvol ? cnt[lane] : 0;
+        const int ng = (c + 15) >> 4;
+        int incl = ng, sincl = c > 0 ? 1 : 0;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            int t = __shfl_up(incl, d, 64);
+            int u = __shfl_up(sincl, d, 64);
+            if (lane >= d) {
+                incl += t;
+                sincl += u;
+            }
+        }
+        gbase[lane] = incl - ng;
+        if (c > 0) soff[sincl - 1] = lane;
+        if (lane == 63) *nsteps_p = sincl;
+    }
+    __syncthreads();
+    // ---- item entries: (input row << 7 | output row of the tile); a group's padding entries
+    //      gather a valid row and dump the result
+#pragma unroll
+    for (int i = 0; i < MAXO; ++i) {
+        const int o = wavew + i * NWT;
+        if (o >= kvol) continue; // wave-uniform
+        const int id = idv[i];
+        const bool has = id >= 0;
+        const unsigned long long m = __ballot(has);
+        if (m == 0ull) continue;
+        const int c = __popcll(m);
+        const int p = __popcll(m & ((1ull << lane) - 1ull));
+        unsigned *dst = ent + gbase[o] * 16;
+        if (has) dst[p] = ((unsigned)id << 7) | (unsigned)lane;
+        const int first = __shfl(id, __builtin_ctzll(m), 64);
+        const int padded = ((c + 15) >> 4) << 4;
+        if (c + lane < padded) dst[c + lane] = ((unsigned)first << 7) | (unsigned)DUMP;
+    }
+    __syncthreads();
+}
+
 // BF16: operands rounded to bf16 (features when they enter LDS, weights in a bf16 image in
 // v_mfma_f32_16x16x32_bf16 fragment order), fp32 accumulation and fp32 output: the training
 // variant BASELINE.json configs[2] names.  Needs Cin a multiple of 32.
@@ -602,7 +687,7 @@ cv_tc_kernel(const float *__restrict__ feat, const float *__restrict__ wimg,
              const int *__restrict__ nbr, int k_cap, const int *__restrict__ k_dev, int kvol,
              int cin, int cout, const float *__restrict__ scale,
              const float *__restrict__ shift, int relu, float *__restrict__ out, int tr,
-             TcDense dn)
+             TcDense dn, const int *__restrict__ plan, int plan_stride)
 {
     using C = TcCfg<CIN, COUT, TR>;
     constexpr int THREADS = C::THREADS, NT = C::NT, KL = C::KL, VW = C::VW, SG = C::SG;
@@ -624,6 +709,9 @@ cv_tc_kernel(const float *__restrict__ feat, const float *__restrict__ wimg,
     // round-robin balances the per-tile work) and no different at batch 8 (294k rows).)
     const int row0 = blockIdx.x * tr;
     if (row0 >= k_out) return;
+#if defined(TC_ABLATE) && TC_ABLATE == 3 // timing ablation: launch + row count only
+    if (k_out >= 0) return;
+#endif
 
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int ASTRH = CIN + 8;                               // bf16 A row stride (halfs)
@@ -654,62 +742,26 @@ cv_tc_kernel(const float *__restrict__ feat, const float *__restrict__ wimg,
     __bf16 *alh = reinterpret_cast<__bf16 *>(smem) + set * ABUFS * NP * APL; // [ABUFS][NP][TR][ASTRH]
     float *ot = ot0 + set * OTE;                                 // this set's output tile
 
-    // ---- neighbour tile -> LDS (coalesced; rows past k_out read as -1)
-    {
-        const int total = tr * kvol;
-        const long long gbase_e = (long long)row0 * kvol;
-        const long long glimit = (long long)k_out * kvol;
-        for (int e = tidw; e < total; e += TT) {
-            int v = -1;
-            if (gbase_e + e < glimit) v = nbr ? nbr[gbase_e + e] : row0 + e; // NULL: identity
-            nl[e] = v;
-        }
+    if (plan) {
+        // the compaction of this tile was done once per rulebook (lcf_conv_tile_plan: shared by the
+        // convs of one indice_key, built beside the feature path): copy its image into LDS
+        const int4 *src = reinterpret_cast<const int4 *>(plan + (size_t)blockIdx.x * plan_stride);
+        int4 *dst = reinterpret_cast<int4 *>(ent);
+        for (int e = tidw; e < plan_stride / 4; e += TT) dst[e] = src[e];
+        __syncthreads();
+    } else {
+        tc_build_steps<NWT, TT>(nbr, row0, tr, kvol, k_out, nl, ent, cnt, gbase, soff, nsteps_p,
+                                DUMP);
     }
-    __syncthreads();
-    // ---- rows per offset
-    for (int o = wavew; o < kvol; o += NWT) {
-        const unsigned long long m = __ballot(lane < tr && nl[lane * kvol + o] >= 0);
-        if (lane == 0) cnt[o] = __popcll(m);
-    }
-    __syncthreads();
-    // ---- steps = active offsets ascending; items = their 16-row groups
-    if (wavew == 0) {
-        const int c = lane < kvol ? cnt[lane] : 0;
-        const int ng = (c + 15) >> 4;
-        int incl = ng, sincl = c > 0 ? 1 : 0;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            int t = __shfl_up(incl, d, 64);
-            int u = __shfl_up(sincl, d, 64);
-            if (lane >= d) {
-                incl += t;
-                sincl += u;
-            }
-        }
-        gbase[lane] = incl - ng;
-        if (c > 0) soff[sincl - 1] = lane;
-        if (lane == 63) *nsteps_p = sincl;
-    }
-    __syncthreads();
-    // ---- item entries: (input row << 7 | output row of the tile); a group's padding entries
-    //      gather a valid row and dump the result
-    for (int o = wavew; o < kvol; o += NWT) {
-        const int id = lane < tr ? nl[lane * kvol + o] : -1;
-        const bool has = id >= 0;
-        const unsigned long long m = __ballot(has);
-        if (m == 0ull) continue;
-        const int c = __popcll(m);
-        const int p = __popcll(m & ((1ull << lane) - 1ull));
-        unsigned *dst = ent + gbase[o] * 16;
-        if (has) dst[p] = ((unsigned)id << 7) | (unsigned)lane;
-        const int first = __shfl(id, __builtin_ctzll(m), 64);
-        const int padded = ((c + 15) >> 4) << 4;
-        if (c + lane < padded) dst[c + lane] = ((unsigned)first << 7) | (unsigned)DUMP;
-    }
-    __syncthreads();
+#if defined(TC_ABLATE) && TC_ABLATE == 5 // timing ablation: ... + counts, steps, entries
+    if (k_out >= 0) return;
+#endif
     for (int e = tidw; e < NSETS * OTE; e += TT) ot0[e] = 0.f; // nl is dead now
     const int n_steps = __builtin_amdgcn_readfirstlane(*nsteps_p);
     __syncthreads();
+#if defined(TC_ABLATE) && TC_ABLATE == 1 // timing ablation: the set-up alone (results wrong)
+    if (n_steps >= 0) return;
+#endif
 
     struct AReg { float4 v[MAXG][APT]; };
     struct BReg {
@@ -952,6 +1004,9 @@ cv_tc_kernel(const float *__restrict__ feat, const float *__restrict__ wimg,
         }
     }
 
+#if defined(TC_ABLATE) && TC_ABLATE == 2 // timing ablation: no epilogue (results wrong)
+    if (k_out >= 0) return;
+#endif
     // ---- epilogue: (x*scale + shift), relu, coalesced store of the tile
     if (cout == COUT) {
         constexpr int C4 = COUT / 4;
@@ -1010,6 +1065,76 @@ cv_tc_kernel(const float *__restrict__ feat, const float *__restrict__ wimg,
     }
 }
 
+// ---- tile plans: the set-up of every tile of a rulebook, computed once (lcf_conv_tile_plan) and
+// read by every tile-compacted launch over that rulebook (the two or three convs of one
+// indice_key, forward passes of later frames never: a plan belongs to one frame's rulebook).
+// One record per tile = the image of the kernel's LDS block: ent [32 * kvol] | cnt [64] |
+// gbase [64] | soff [64] | nsteps, padded to 16 bytes.
+static int tc_plan_stride(int kvol) { return (32 * kvol + 193 + 3) & ~3; }
+static int tc_tile_rows(int rows);
+
+__global__ void __launch_bounds__(256)
+cv_plan_kernel(const int *__restrict__ nbr, int k_cap, const int *__restrict__ k_dev, int kvol,
+               int tr, int *__restrict__ plan, int plan_stride)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    int *nl = reinterpret_cast<int *>(smem);                   // [32][kvol]
+    unsigned *ent = reinterpret_cast<unsigned *>(nl + ((32 * kvol + 3) & ~3));
+    int *cnt = reinterpret_cast<int *>(ent + 32 * kvol);
+    int *gbase = cnt + 64;
+    int *soff = gbase + 64;
+    int *nsteps_p = soff + 64;
+    const int k_out = lcf_count(k_cap, k_dev);
+    const int row0 = blockIdx.x * tr;
+    int4 *dst = reinterpret_cast<int4 *>(plan + (size_t)blockIdx.x * plan_stride);
+    if (row0 >= k_out) { // the conv kernels leave such a tile before reading its record
+        return;
+    }
+    for (int e = threadIdx.x; e < 32 * kvol; e += 256) ent[e] = 0u; // unused entries: defined
+    if (threadIdx.x < 64) {
+        cnt[threadIdx.x] = 0;
+        gbase[threadIdx.x] = 0;
+        soff[threadIdx.x] = 0;
+    }
+    __syncthreads();
+    tc_build_steps<4, 256>(nbr, row0, tr, kvol, k_out, nl, ent, cnt, gbase, soff, nsteps_p, 32);
+    const int4 *src = reinterpret_cast<const int4 *>(ent);
+    for (int e = threadIdx.x; e < plan_stride / 4; e += 256) dst[e] = src[e];
+}
+
+extern "C" size_t lcf_conv_tile_plan_ints(int k_cap, int kvol, int tile_rows)
+{
+    if (k_cap < 0 || kvol <= 0 || kvol > LCF_MAX_KVOL || tile_rows < 1 || tile_rows > 32) return 0;
+    const size_t tiles = ((size_t)k_cap + tile_rows - 1) / tile_rows;
+    return (tiles ? tiles : 1) * (size_t)tc_plan_stride(kvol);
+}
+
+extern "C" int lcf_conv_tile_rows(int rows)
+{
+    // the height the tile-compacted forward picks for a launch that expects `rows` rows
+    LcfCall call(nullptr);
+    call.eff.conv_tile = 0;
+    return tc_tile_rows(rows);
+}
+
+extern "C" int lcf_conv_tile_plan(const int *nbr, int k, const int *k_dev, int kvol,
+                                  int tile_rows, int *plan, void *stream)
+{
+    if (k < 0 || kvol <= 0 || tile_rows < 1 || tile_rows > 32 || !plan || (k > 0 && !nbr) ||
+        ((uintptr_t)plan & 15))
+        return LCF_ERR_ARG;
+    if (kvol > LCF_MAX_KVOL) return LCF_ERR_UNSUPPORTED;
+    if (k >= (1 << 25)) return LCF_ERR_RANGE;
+    if (k == 0) return LCF_OK;
+    const int nb = (k + tile_rows - 1) / tile_rows;
+    const int stride = tc_plan_stride(kvol);
+    const size_t lds = (size_t)(((32 * kvol + 3) & ~3) + stride + 4) * 4;
+    cv_plan_kernel<<<nb, 256, lds, (hipStream_t)stream>>>(nbr, k, k_dev, kvol, tile_rows, plan,
+                                                          stride);
+    LCF_CHECK_LAUNCH();
+    return LCF_OK;
+}
+
 // Launch-time choices come from the options of the call in progress (lcf_opts(), common.h):
 // conv_tile (LCF_OPT_CONV_TILE: 0 = balance over the CUs, 16..32 = fixed height), conv_sets
 // (LCF_OPT_CONV_SETS: 0 = choose from the row count, 1 or 2 wave sets), rows_hint
@@ -1046,16 +1171,24 @@ static int cv_launch_tc_n(const float *feat, const float *wimg, const int *nbr, 
     if (dn.coors && cout != COUT) return LCF_ERR_UNSUPPORTED;
     int nb = (k_cap + tr - 1) / tr;
     constexpr int TT = C::THREADS * NSETS;
+    // a tile plan (lcf_conv_tile_plan) of the call in progress replaces the per-launch set-up
+    const LcfOpts op = lcf_opts();
+    const int *plan = op.plan;
+    const int pstride = plan ? tc_plan_stride(kvol) : 0;
+    if (plan && (op.plan_tr != tr || TR != 32)) return LCF_ERR_ARG;
     if constexpr (BF16) {
         if (cin != CIN) return LCF_ERR_UNSUPPORTED;
         cv_tc_kernel<CIN, COUT, TR, true, true, NSETS, NP><<<nb, TT, lds, st>>>(
-            feat, wimg, nbr, k_cap, k_dev, kvol, cin, cout, scale, shift, relu, out, tr, dn);
+            feat, wimg, nbr, k_cap, k_dev, kvol, cin, cout, scale, shift, relu, out, tr, dn, plan,
+            pstride);
     } else if (cin == CIN)
         cv_tc_kernel<CIN, COUT, TR, true, false, NSETS, 1><<<nb, TT, lds, st>>>(
-            feat, wimg, nbr, k_cap, k_dev, kvol, cin, cout, scale, shift, relu, out, tr, dn);
+            feat, wimg, nbr, k_cap, k_dev, kvol, cin, cout, scale, shift, relu, out, tr, dn, plan,
+            pstride);
     else
         cv_tc_kernel<CIN, COUT, TR, false, false, NSETS, 1><<<nb, TT, lds, st>>>(
-            feat, wimg, nbr, k_cap, k_dev, kvol, cin, cout, scale, shift, relu, out, tr, dn);
+            feat, wimg, nbr, k_cap, k_dev, kvol, cin, cout, scale, shift, relu, out, tr, dn, plan,
+            pstride);
     LCF_CHECK_LAUNCH();
     return LCF_OK;
 }
@@ -1065,7 +1198,9 @@ static int cv_launch_tc_n(const float *feat, const float *wimg, const int *nbr, 
 // long as the CUs with 3; 744 tiles of 25 rows are 3 everywhere, each 22% shorter).
 static int tc_tile_rows(int rows)
 {
-    const int fixed = lcf_opts().conv_tile;
+    const LcfOpts op = lcf_opts();
+    if (op.plan) return op.plan_tr; // the plan was built for this height
+    const int fixed = op.conv_tile;
     if (fixed >= 16 && fixed <= 32) return fixed;
     const int per_round = 256;
     const int m = (rows + per_round * 32 - 1) / (per_round * 32); // tiles per CU at 32 rows
@@ -1158,16 +1293,16 @@ static int cv_launch_tc_bf16(const float *feat, const float *wimg, const int *nb
 {
     // (64-row tiles, which halve the W stream per row, were measured at batch 8: 212 -> 286 us
     // on the 64->64 layers -- fewer, longer chains per CU lose more than the traffic saves)
+    const LcfOpts op = lcf_opts();
     return cv_launch_tc_n<CIN, COUT, 32, true>(feat, wimg, nbr, k_cap, k_dev, kvol, cin, cout,
-                                               scale, shift, relu, out, st);
+                                               scale, shift, relu, out, st,
+                                               op.plan ? op.plan_tr : 32);
 }
 
-extern "C" int lcf_indice_conv_fwd_bf16(const float *feat, const void *wimg_bf16, const int *nbr,
-                                        int k_out, const int *k_out_dev, int kvol, int cin,
-                                        int cout, const float *scale, const float *shift,
-                                        int relu, float *out, void *stream, lcf_ctx *ctx)
+static int cv_fwd_bf16(const float *feat, const void *wimg_bf16, const int *nbr, int k_out,
+                       const int *k_out_dev, int kvol, int cin, int cout, const float *scale,
+                       const float *shift, int relu, float *out, void *stream)
 {
-    LcfCall call(ctx);
     if (k_out < 0 || kvol <= 0 || !wimg_bf16 || (k_out > 0 && (!feat || !out)) ||
         (!nbr && kvol != 1))
         return LCF_ERR_ARG;
@@ -1188,6 +1323,16 @@ extern "C" int lcf_indice_conv_fwd_bf16(const float *feat, const void *wimg_bf16
     CV_BF16_CASE(128, 32) CV_BF16_CASE(128, 64) CV_BF16_CASE(128, 128)
 #undef CV_BF16_CASE
     return LCF_ERR_UNSUPPORTED;
+}
+
+extern "C" int lcf_indice_conv_fwd_bf16(const float *feat, const void *wimg_bf16, const int *nbr,
+                                        int k_out, const int *k_out_dev, int kvol, int cin,
+                                        int cout, const float *scale, const float *shift,
+                                        int relu, float *out, void *stream, lcf_ctx *ctx)
+{
+    LcfCall call(ctx);
+    return cv_fwd_bf16(feat, wimg_bf16, nbr, k_out, k_out_dev, kvol, cin, cout, scale, shift,
+                       relu, out, stream);
 }
 
 // -------------------------------------------------------------------------- bf16x3 entry points
@@ -1798,6 +1943,50 @@ extern "C" int lcf_indice_conv_fwd_dense(const float *feat, const float *wimg, c
     const TcDense dn{out_coors, batch, shape[0], shape[1], shape[2]};
     CV_DISPATCH(cv_launch_tc, feat, wimg, nbr, k_out, k_out_dev, kvol, cin, cout, scale, shift,
                 relu, dense, (hipStream_t)stream, dn);
+}
+
+// Forward over a tile plan (lcf_conv_tile_plan) instead of a neighbour table: the same kernels and
+// the same arithmetic, bit for bit, without the per-launch compaction of each tile.  math 0: fp32
+// MFMA (lcf_indice_conv_fwd / _dense), 1: bf16 operands, 2: bf16x3, 3: bf16x8 (wimg is the image
+// of that form).  Shapes the tile-compacted kernels serve: cin, cout in {32, 64, 128}.
+extern "C" int lcf_indice_conv_fwd_planned(const float *feat, const void *wimg, int math,
+                                           const int *plan, int tile_rows, int k_out,
+                                           const int *k_out_dev, int kvol, int cin, int cout,
+                                           const float *scale, const float *shift, int relu,
+                                           float *out, const int *dense_coors, int batch,
+                                           const int shape[3], void *stream, lcf_ctx *ctx)
+{
+    LcfCall call(ctx);
+    if (!plan || ((uintptr_t)plan & 15) || tile_rows < 1 || tile_rows > 32 || math < 0 || math > 3)
+        return LCF_ERR_ARG;
+    if (!cv_bf16_ok(cin) || !cv_bf16_ok(cout)) return LCF_ERR_UNSUPPORTED;
+    call.eff.plan = plan;
+    call.eff.plan_tr = tile_rows;
+    call.eff.conv_impl = 2; // tile-compacted
+    const int *nbr = plan;  // never read: the kernels take the plan's entries
+    if (math == 0) {
+        if (k_out < 0 || kvol <= 0 || !wimg || (k_out > 0 && (!feat || !out)) ||
+            (dense_coors && (!shape || batch <= 0)))
+            return LCF_ERR_ARG;
+        if (kvol > LCF_MAX_KVOL) return LCF_ERR_UNSUPPORTED;
+        if (((uintptr_t)feat & 15) || ((uintptr_t)wimg & 15) || ((uintptr_t)out & 15) ||
+            ((uintptr_t)scale & 15) || ((uintptr_t)shift & 15) || ((uintptr_t)dense_coors & 15))
+            return LCF_ERR_ARG;
+        if (k_out >= (1 << 25)) return LCF_ERR_RANGE;
+        if (k_out == 0) return LCF_OK;
+        const int CIN = cin, COUT = cout;
+        TcDense dn{nullptr, 0, 0, 0, 0};
+        if (dense_coors) dn = TcDense{dense_coors, batch, shape[0], shape[1], shape[2]};
+        CV_DISPATCH(cv_launch_tc, feat, (const float *)wimg, nbr, k_out, k_out_dev, kvol, cin,
+                    cout, scale, shift, relu, out, (hipStream_t)stream, dn);
+    }
+    if (math == 1) {
+        if (dense_coors) return LCF_ERR_UNSUPPORTED;
+        return cv_fwd_bf16(feat, wimg, nbr, k_out, k_out_dev, kvol, cin, cout, scale, shift, relu,
+                           out, stream);
+    }
+    return cv_fwd_split(feat, wimg, nbr, k_out, k_out_dev, kvol, cin, cout, scale, shift, relu,
+                        out, dense_coors, batch, shape, stream, math == 3 ? 3 : 2);
 }
 
 template <int CIN, int COUT>

@@ -469,7 +469,27 @@ extern "C" int lcf_rulebook_chain(const int *coors, int k, const int *k_dev, int
         R.cand_slot = p.w.cand_slot;
         blocks += rbc_blocks(p.w.total);
     };
+    // rows of the level a table belongs to: (capacity, device count)
+    int rows_cap[64];
+    const int *rows_dev[64];
+    {
+        int cap = k;
+        const int *dev = k_dev;
+        for (int q = 0; q < n; ++q) {
+            if (!lv[q].subm) {
+                cap = lv[q].cap_out;
+                dev = lv[q].k_out;
+            }
+            rows_cap[q] = cap;
+            rows_dev[q] = dev;
+        }
+    }
     auto record = [&](int i) -> int {
+        if (lv[i].plan) { // the conv kernels' per-tile set-up, once per rulebook
+            int rc = lcf_conv_tile_plan(lv[i].out_nbr, rows_cap[i], rows_dev[i], plan[i].g.kvol,
+                                        lv[i].plan_tile_rows, lv[i].plan, stream);
+            if (rc) return rc;
+        }
         if (lv[i].ready_event &&
             hipEventRecord((hipEvent_t)lv[i].ready_event, st) != hipSuccess)
             return LCF_ERR_LAUNCH;

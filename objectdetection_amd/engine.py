@@ -247,8 +247,22 @@ class FrameEngine:
                                   dilation=l.dil))
                 cap = l.k_out_cap
             l.out = E(l.k_out_cap, l.cout)
+        # tile plans: the tile-compacted convs' per-tile set-up depends on the rulebook only, so the
+        # chain builds it once per rulebook (beside the feature path) instead of every launch
+        # re-deriving it; the tile height is the one the forward would pick for the rows expected
+        plan_rows, lvl = {}, 0
+        self.use_plans = os.environ.get("LCF_ENGINE_TILE_PLANS", "1") != "0"
+        for l in self.layers:
+            if not l.subm:
+                lvl += 1
+            l.planned = (self.use_plans and l.kvol > 1 and
+                         ops.bf16_supported(l.cin, l.cout))
+            if l.planned:
+                need = getattr(self, "level_need", None)
+                rows = int(need[lvl]) if need else l.k_out_cap
+                plan_rows[l.rb_owner.level] = L.lcf_conv_tile_rows(min(rows, l.k_out_cap))
         self.chain = ops.RulebookChain(
-            specs, MV, 1, self.sparse_shape, device=dev,
+            specs, MV, 1, self.sparse_shape, device=dev, plan_rows=plan_rows,
             caps=[l.k_out_cap for l in self.layers if not l.subm])
         self.flags = self.chain.flags
         self.level_caps = [MV]
@@ -394,7 +408,15 @@ class FrameEngine:
             to_dense = l is self.layers[-1] and self.fuse_dense and l.cout in (16, 32, 64, 128)
             if to_dense and self.two_streams:
                 main.wait_event(e_dense)
-            if l.x3:
+            if l.planned:
+                lv = o.level
+                check(L.lcf_indice_conv_fwd_planned(
+                    P(feat), P(l.wimg), (3 if l.planes == 3 else 2) if l.x3 else 0,
+                    P(self.chain.plan[lv]), self.chain.plan_rows[lv], k_out_cap, P(k_out_dev),
+                    l.kvol, l.cin, l.cout, P(l.scale), P(l.shift), int(l.relu),
+                    P(self.dense if to_dense else l.out), P(coors) if to_dense else None, 1,
+                    i3(self.out_shape), st, cx))
+            elif l.x3:
                 fwd_split = L.lcf_indice_conv_fwd_bf16x8 if l.planes == 3 \
                     else L.lcf_indice_conv_fwd_bf16x3
                 check(fwd_split(

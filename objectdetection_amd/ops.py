@@ -215,7 +215,10 @@ class RulebookChain:
     level i holds ``out_nbr[i]`` [rows_cap, kvol]; strided levels also ``out_coors[i]``,
     ``k_out[i]`` (device count) and their entry of ``flags`` (overflow)."""
 
-    def __init__(self, specs, k_cap, batch_size, spatial_shape, caps=None, device=None):
+    def __init__(self, specs, k_cap, batch_size, spatial_shape, caps=None, device=None,
+                 plan_rows=None):
+        """plan_rows: {level: tile height} -- levels whose conv tile plan
+        (lcf_conv_tile_plan) the chain should build as well (``plan[level]``)."""
         L = _lib.lib()
         dev = torch.device("cuda", torch.cuda.current_device()) if device is None else device
         self.L, self.dev = L, dev
@@ -223,6 +226,7 @@ class RulebookChain:
         self.n = len(specs)
         self.levels = (_lib.RbLevel * self.n)()
         self.out_nbr, self.out_coors, self.k_out, self.ws = {}, {}, {}, {}
+        self.plan, self.plan_rows = {}, {}
         self.rows_cap, self.kvol, self.out_shape = [], [], []
         self.strided = [i for i, sp in enumerate(specs) if not sp["subm"]]
         self.flags = torch.zeros(max(len(self.strided), 1), dtype=torch.int32, device=dev)
@@ -261,6 +265,12 @@ class RulebookChain:
             lv.out_nbr = self.out_nbr[i].data_ptr()
             self.rows_cap.append(cap)
             self.out_shape.append(list(shape))
+            if plan_rows and i in plan_rows:
+                tr = int(plan_rows[i])
+                self.plan[i] = torch.zeros(L.lcf_conv_tile_plan_ints(cap, kvol, tr), dtype=i32,
+                                           device=dev)
+                self.plan_rows[i] = tr
+                lv.plan, lv.plan_tile_rows = self.plan[i].data_ptr(), tr
         self.ws0 = _ws(L.lcf_rulebook_subm_workspace_bytes(self.k_cap), dev)
 
     def set_event(self, i, event):
