@@ -30,17 +30,24 @@ from objectdetection_amd.frontend import SparseFrontEnd, randomize_  # noqa: E40
 F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md "Peak FP32 (matrix)"
 
 
-def dominant_kernel_roofline(model, cloud, reps=20):
-    """Times every launch of the dominant kernel -- cv_tc_kernel<64,64,32>, the 64->64 channel
-    indice_conv (fused gather-GEMM-scatter + BN + ReLU) -- with HIP events on the stream it is
-    launched on, after the timed region.  achieved = algorithmic flops per launch
-    (2 * pairs * Cin * Cout) / average launch duration."""
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md "Peak BF16/FP16 MFMA" (dense)
+HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md "HBM3E peak BW" (spec)
+
+
+def dominant_kernel_roofline(model, clouds, math="f32", reps=20):
+    """Times every launch of the dominant kernel -- the 64->64 channel indice_conv (fused
+    gather-GEMM-scatter + BN + ReLU), cv_tc_kernel<64,64,32>: fp32 MFMA over tile plans as
+    FrameEngine launches it (math "f32"), or with bf16 MFMA operands over neighbour tables as the
+    training step launches it (math "bf16") -- with HIP events on the stream it is launched on,
+    after the timed region.  achieved = algorithmic flops per launch (2 * pairs * Cin * Cout,
+    SURVEY.md section 8d) / average launch duration; the same launches priced in algorithmic
+    bytes (K_in*Cin*4 + K_out*Cout*4 + K_out*kvol*4 + kvol*Cin*Cout*e) against HBM."""
     from objectdetection_amd.spconv import SparseConvTensor
     from objectdetection_amd.spconv.modules import _bn_affine
     mid = model.middle_feature_extractor
-    voxels, num, coors = model.voxelize([cloud])
+    voxels, num, coors = model.voxelize(clouds)
     feats = model.voxel_feature_extractor(voxels, num, coors)
-    x = SparseConvTensor(feats, coors, mid.sparse_shape, 1)
+    x = SparseConvTensor(feats, coors, mid.sparse_shape, len(clouds))
     mods = list(mid.middle_conv)
     launches = []
     i = 0
@@ -48,42 +55,74 @@ def dominant_kernel_roofline(model, cloud, reps=20):
         conv, bn = mods[i], mods[i + 1]
         rb = conv.get_rulebook(x)
         scale, shift = _bn_affine(bn)
-        args = (x.features, conv._weight_image(), rb.out_nbr, rb.k_out, rb.kvol,
-                conv.in_channels, conv.out_channels, scale, shift, True)
         if conv.in_channels == 64 and conv.out_channels == 64:
             pairs = int((rb.out_nbr >= 0).sum().item())
-            launches.append((args, pairs, rb.k_in, rb.k_out))
+            nbytes = 4 * (rb.k_in * 64 + rb.k_out * 64 + rb.k_out * rb.kvol) + \
+                rb.kvol * 64 * 64 * (4 if math == "f32" else 2)
+            if math == "f32":
+                plan, tr = ops.tile_plan(rb.out_nbr, rb.k_out, rb.kvol)
+                call = (ops.conv_forward_planned,
+                        (x.features, conv._weight_image(), plan, tr, rb.k_out, rb.kvol, 64, 64,
+                         scale, shift, True))
+            else:
+                call = (ops.conv_forward_bf16,
+                        (x.features, ops.weight_image_bf16(conv.weight), rb.out_nbr, rb.k_out,
+                         rb.kvol, 64, 64, scale, shift, True))
+            launches.append((call, pairs, nbytes))
         x = conv(x, _scale=scale, _shift=shift, _relu=True)
         i += 3
     torch.cuda.synchronize()
-    total_ms, total_flops, n = 0.0, 0.0, 0
+    total_ms, total_flops, total_bytes, n = 0.0, 0.0, 0.0, 0
     stream = torch.cuda.current_stream()
-    for args, pairs, _, _ in launches:
-        ops.conv_forward(*args)  # warm
+    for (fn, args), pairs, nbytes in launches:
+        fn(*args)  # warm
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)
         e0.record(stream)
         for _ in range(reps):
-            ops.conv_forward(*args)
+            fn(*args)
         e1.record(stream)
         e1.synchronize()
         total_ms += e0.elapsed_time(e1) / reps
         total_flops += 2.0 * pairs * 64 * 64
+        total_bytes += nbytes
         n += 1
     avg_s = total_ms / n * 1e-3
-    achieved = total_flops / n / avg_s / 1e12
+    tflops = total_flops / n / avg_s / 1e12
+    gbs = total_bytes / n / avg_s / 1e9
     traffic = None  # HBM bytes per launch from the committed PMC passes (tools/pmc_summary.py)
-    try:
-        with open(os.path.join(ROOT, "profiles", "pmc_dominant_kernel.json")) as fh:
-            traffic = json.load(fh)["hbm_bytes_per_launch"]
-    except (OSError, KeyError, ValueError):
-        pass
-    return {"bound": "mfma", "achieved": round(achieved, 3), "peak": F32_MFMA_PEAK_TFLOPS,
-            "unit": "TFLOP/s", "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4),
-            "traffic": traffic,
-            "kernel": "cv_tc_kernel<64,64,32>", "launches_per_frame": n,
-            "avg_launch_us": round(avg_s * 1e6, 2),
-            "flops_per_launch": round(total_flops / n, 0)}
+    if math == "f32":
+        try:
+            with open(os.path.join(ROOT, "profiles", "pmc_dominant_kernel.json")) as fh:
+                traffic = json.load(fh)["hbm_bytes_per_launch"]
+        except (OSError, KeyError, ValueError):
+            pass
+    common = {"kernel": "cv_tc_kernel<64,64,32>" + ("" if math == "f32" else " (bf16 operands)"),
+              "launches_per_frame" if math == "f32" else "launches_timed": n,
+              "avg_launch_us": round(avg_s * 1e6, 2),
+              "flops_per_launch": round(total_flops / n, 0),
+              "algorithmic_bytes_per_launch": round(total_bytes / n, 0),
+              "intensity_flop_per_byte": round(total_flops / total_bytes, 1)}
+    if math == "f32":
+        # 165 flop/B against a ridge of 157.3 TF / 8 TB/s = 20 flop/B: priced against the fp32
+        # MFMA peak (SURVEY.md 8d's "grade against HBM" assumed Cin, Cout <= 64 made it
+        # bandwidth-bound; its own byte formula says otherwise); the HBM view is reported too
+        return {"bound": "mfma", "achieved": round(tflops, 3), "peak": F32_MFMA_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(tflops / F32_MFMA_PEAK_TFLOPS, 4),
+                "traffic": traffic,
+                "bound_rationale": "algorithmic intensity above the fp32 ridge (157.3 TFLOP/s / "
+                                   "8 TB/s = 19.7 flop/B): MFMA-bound; fp32 MFMA and VALU share "
+                                   "one datapath on gfx950 (DESIGN.md section 4)",
+                "hbm_view": {"achieved_GBs": round(gbs, 1), "frac_of_8TBs": round(gbs / HBM_PEAK_GBS, 4)},
+                **common}
+    # bf16 operands: ridge 2500 TF / 8 TB/s = 312 flop/B, above the kernel's intensity: HBM-bound
+    return {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
+            "bound_rationale": "algorithmic intensity below the bf16 ridge (2500 TFLOP/s / 8 TB/s "
+                               "= 312 flop/B): priced against HBM",
+            "mfma_view": {"achieved_TFLOPs": round(tflops, 2),
+                          "frac_of_bf16_peak": round(tflops / BF16_MFMA_PEAK_TFLOPS, 4)},
+            **common}
 
 
 def cpu_baseline(model_name, cloud_np, budget_s, max_voxels=40000):
@@ -122,7 +161,14 @@ def train_measurement(args, dev, rank, world, dist, barrier):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
     nparams = sum(p.numel() for p in step.net.parameters())
-    return {"metric": "frames/s training step (VFE + sparse middle fwd/dgrad/wgrad + RPNV2)",
+    roof = None
+    if rank == 0:  # the step's dominant kernel on one of its batches (profiles/r02_train_*)
+        with torch.no_grad():
+            step.net.eval()
+            roof = dominant_kernel_roofline(step.net.frontend, batches[0], math="bf16", reps=10)
+            step.net.train()
+    return {"roofline": roof,
+            "metric": "frames/s training step (VFE + sparse middle fwd/dgrad/wgrad + RPNV2)",
             "value": round(world * b * args.train_steps / el, 2), "unit": "frames/s",
             "ms_per_step": round(el / args.train_steps * 1e3, 2), "steps": args.train_steps,
             "global_batch": world * b, "scaling": "weak",
@@ -272,7 +318,7 @@ def main(argv=None):
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
         assert out.shape[1:] == (128, 200, 176) or args.model == "M3", out.shape
-        roof = dominant_kernel_roofline(model, clouds[0]) if rank == 0 and args.model != "M3" \
+        roof = dominant_kernel_roofline(model, [clouds[0]]) if rank == 0 and args.model != "M3" \
             else None
         # secondary lines (never `value`): the same frames through engines whose wide sparse
         # convs run split-operand math on the bf16 matrix cores -- "bf16x8" (three exact planes,

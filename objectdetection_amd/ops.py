@@ -435,6 +435,34 @@ def conv_forward(features, wimg, nbr, n_rows, kvol, cin, cout, scale=None, shift
     return out
 
 
+def tile_plan(nbr, n_rows, kvol, k_dev=None):
+    """nbr [rows_cap, kvol] -> (plan, tile_rows): the tile-compacted kernels' per-tile set-up for
+    this table (include/lcf.h: lcf_conv_tile_plan), shared by every conv over it."""
+    _need_cuda(nbr)
+    L = _lib.lib()
+    tr = L.lcf_conv_tile_rows(int(n_rows))
+    plan = torch.zeros(L.lcf_conv_tile_plan_ints(int(n_rows), int(kvol), tr), dtype=torch.int32,
+                       device=nbr.device)
+    check(L.lcf_conv_tile_plan(_ptr(nbr), int(n_rows), _ptr(k_dev), int(kvol), tr, _ptr(plan),
+                               _stream()))
+    return plan, tr
+
+
+def conv_forward_planned(features, wimg, plan, tile_rows, n_rows, kvol, cin, cout, scale=None,
+                         shift=None, relu=False, math=0, out=None, k_dev=None, ctx=None):
+    """lcf_indice_conv_fwd_planned: the forward over a tile plan; math 0 fp32, 1 bf16, 2 bf16x3,
+    3 bf16x8 (wimg in that form).  Bit-identical to the table forward of the same form."""
+    _need_cuda(features, wimg, plan)
+    x = features.contiguous()
+    if out is None:
+        out = torch.empty((int(n_rows), cout), dtype=torch.float32, device=x.device)
+    check(_lib.lib().lcf_indice_conv_fwd_planned(
+        _ptr(x), _ptr(wimg), int(math), _ptr(plan), int(tile_rows), int(n_rows), _ptr(k_dev),
+        int(kvol), int(cin), int(cout), _ptr(scale), _ptr(shift), int(bool(relu)), _ptr(out), None,
+        1, i3(0), _stream(), ctx))
+    return out
+
+
 def conv_forward_dense(features, wimg, nbr, n_rows, kvol, cin, cout, out_coors, batch_size,
                        shape, scale=None, shift=None, relu=False, n_rows_dev=None, out=None):
     """conv_forward whose rows land in a dense [batch, cout, D, H, W] tensor at ``out_coors``
