@@ -487,6 +487,31 @@ int lcf_nms(const float *dets, int n, int stride, int mode, float thresh, float 
             int inclusive, int max_keep, int *keep, int *num_keep, void *ws, size_t ws_bytes,
             void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Light-curtain placement next to the detector: what LC_PROCESS
+ * (second/light_curtain/utils.py:88-104) does on the host between two detector passes.
+ * lcf_lc_entropy_lookup replaces torch.sigmoid(cls_preds).cpu() + _get_confidence_map's masking
+ *   and flip (utils.py:93-95, 208-235) + Policy.confidence2entropy (policy.py:60-66) +
+ *   DPOptimizedPolicy._umap2ulookup (policy.py:154-158): cls [K,Y,X] f32 class scores (logits
+ *   when apply_sigmoid != 0), anchors_mask [K,Y,X] u8 or NULL; ulookup [Y*X + 1] f32 with
+ *   ulookup[0] = 0 and ulookup[1 + xi*X + zi] = mean_k H(clip(p_k, 1e-5, 1 - 1e-5)) of the cell at
+ *   camera-x index xi = Y-1-y, camera-z index zi = x.
+ * lcf_lc_dp_design replaces DPOptimizedPolicy.get_design_points (policy.py:283-434) given the
+ *   cached graph (policy.py:160-281, built on the host from the device geometry): node_k [T,N]
+ *   i32 = index of every ray point into ulookup, theta_las [T,N] f64 = its laser angle in degrees,
+ *   max_dtheta = laser_vel_limit * laser_timestep; choice [T] i32 = the point chosen on each
+ *   ray t (rays in the graph's order; the reference returns their (x, z) flipped).  Value
+ *   functions in float32 (uncertainty) and float64 (laser cost) as numpy computes them: the
+ *   trajectory is the reference's, tie-breaks included.  N <= 256.  ws:
+ *   lcf_lc_dp_workspace_bytes(T, N).  One workgroup: latency ~0.3 us per ray. */
+int lcf_lc_entropy_lookup(const float *cls, int K, int Y, int X,
+                          const unsigned char *anchors_mask, int apply_sigmoid, float *ulookup,
+                          void *stream);
+size_t lcf_lc_dp_workspace_bytes(int T, int N);
+int lcf_lc_dp_design(const float *ulookup, const int *node_k, const double *theta_las, int T,
+                     int N, double max_dtheta, int *choice, void *ws, size_t ws_bytes,
+                     void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,137 @@
+"""GPU: lcf_lc_entropy_lookup / lcf_lc_dp_design (through the C ABI, behind the reference's policy
+interface) against the reference-run fixtures (tests/golden/lc_policy_golden.npz) and the numpy
+oracle.  Index work (the DP: choice per ray, value functions) is bit-exact given the same
+look-up table; the entropy table is float32 transcendental arithmetic: |diff| <= 2e-6 (log2f on
+the device vs numpy's)."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from objectdetection_amd import _lib
+from objectdetection_amd import light_curtain as lc
+from oracle import lc_policy_oracle as O
+from test_lc_policy import LC_CASES, lc_case
+
+pytestmark = pytest.mark.gpu
+ENTROPY_ATOL = 2e-6
+
+
+def _device(c):
+    return types.SimpleNamespace(CAMERA_PARAMS=c["cam"],
+                                 TRANSFORMS={"cTl": c["cTl"], "wTc": c["wTc"]})
+
+
+def _dp(cuda, ul, node_k, theta, max_dtheta):
+    L = _lib.lib()
+    T, N = node_k.shape
+    ws = torch.zeros(L.lcf_lc_dp_workspace_bytes(T, N), dtype=torch.uint8, device=cuda)
+    choice = torch.empty(T, dtype=torch.int32, device=cuda)
+    ul_d = torch.from_numpy(ul).to(cuda)
+    nk = torch.from_numpy(node_k.astype(np.int32)).to(cuda)
+    th = torch.from_numpy(np.ascontiguousarray(theta)).to(cuda)
+    _lib.check(L.lcf_lc_dp_design(ul_d.data_ptr(), nk.data_ptr(), th.data_ptr(), T, N,
+                                  float(max_dtheta), choice.data_ptr(), ws.data_ptr(),
+                                  ws.numel(), torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    a = (T * N * 4 + 255) // 256 * 256
+    b = (N * 4 + 255) // 256 * 256
+    vu = ws[a:a + N * 4].view(torch.float32).cpu().numpy()
+    vl = ws[a + b:a + b + N * 8].view(torch.float64).cpu().numpy()
+    return choice.cpu().numpy(), vu, vl
+
+
+@pytest.mark.parametrize("name", LC_CASES)
+def test_dp_kernel_is_the_reference_dp_given_the_same_lookup(cuda, name):
+    c = lc_case(name)
+    nodes = c["nodes"]
+    _, theta = O.build_graph(c["confidence_map"][:, :, :2], c["cam"], c["cTl"],
+                             int(c["pts_per_cam_ray"]))
+    ul = O.entropy_lookup(c["confidence_map"])
+    node_k = nodes[:, :, 4].astype(np.int64)
+    want, wu, wl = O.dp_design(ul, node_k, theta, float(c["max_dtheta"]))
+    got, vu, vl = _dp(cuda, ul, node_k, theta, float(c["max_dtheta"]))
+    assert np.array_equal(got, want)
+    assert np.array_equal(vu.view(np.uint32), wu.view(np.uint32))
+    assert np.array_equal(vl.view(np.uint64), wl.view(np.uint64))
+    pts = np.flip(nodes[np.arange(len(got)), got, :2], axis=0)
+    assert np.array_equal(pts, c["design_points"])  # = the reference's own output
+
+
+def test_dp_kernel_long_graph_keeps_next_idx_in_global_memory(cuda):
+    """T*N beyond what LDS holds (a 1242-pixel-wide camera, 130 points per ray): the kernel's
+    other branch.  Synthetic look-up table with many exact ties; checked against the oracle."""
+    c = lc_case("kitti")
+    cam, tr = O.device_geometry(width=1242, height=375, fov=81.16352842604304, laser_y=-0.2)
+    nodes, theta = O.build_graph(c["confidence_map"][:, :, :2], cam, tr["cTl"], 130)
+    node_k = nodes[:, :, 4].astype(np.int64)
+    rng = np.random.default_rng(7)
+    ul = (rng.integers(0, 6, size=1 + 200 * 176) / 8).astype(np.float32)
+    ul[0] = 0
+    want, wu, wl = O.dp_design_vec(ul, node_k, theta, 0.21)
+    got, vu, vl = _dp(cuda, ul, node_k, theta, 0.21)
+    assert np.array_equal(got, want)
+    assert np.array_equal(vu.view(np.uint32), wu.view(np.uint32))
+    assert np.array_equal(vl.view(np.uint64), wl.view(np.uint64))
+
+
+@pytest.mark.parametrize("name", LC_CASES)
+def test_entropy_lookup_matches_confidence_map_path(cuda, name):
+    c = lc_case(name)
+    K = int(c["K"])
+    Y, X = c["centres"].shape[:2]
+    pol = lc.DPOptimizedPolicy(_device(c), int(c["pts_per_cam_ray"]))
+    want = O.entropy_lookup(c["confidence_map"])
+    # (1) the reference's call: the host confidence map
+    got = pol.confidence2entropy(c["confidence_map"]).cpu().numpy()
+    assert got[0] == 0 and np.abs(got - want).max() <= ENTROPY_ATOL
+    # (2) the device path: raw scores + anchors mask, masking and flip on the device
+    cls = torch.from_numpy(c["cls"]).to(cuda)
+    mask = None if c["mask"] is None else torch.from_numpy(c["mask"]).to(cuda)
+    got2 = pol.entropy_lookup(cls, mask, apply_sigmoid=False).cpu().numpy()
+    assert np.array_equal(got2, got)
+    # (3) logits in, sigmoid on the device (utils.py:95)
+    p = np.clip(c["cls"].astype(np.float64), 1e-6, 1 - 1e-6)
+    logits = torch.from_numpy(np.log(p / (1 - p)).astype(np.float32)).to(cuda)
+    got3 = pol.entropy_lookup(logits, mask, apply_sigmoid=True).cpu().numpy()
+    cm3 = O.confidence_map(c["anchors"], c["mask"], torch.sigmoid(logits).cpu().numpy(), c["wTc"])
+    assert np.abs(got3 - O.entropy_lookup(cm3)).max() <= 1e-5
+
+
+@pytest.mark.parametrize("name", LC_CASES)
+def test_policy_end_to_end_against_reference_design_points(cuda, name):
+    """get_design_points(confidence_map) as LC_PROCESS calls it (utils.py:104).  The entropy table
+    differs from numpy's in the last float32 bits, so an exactly tied choice may resolve to another
+    point of equal merit: the summed entropy along the trajectory must equal the reference's to
+    1e-4 relative, and the points themselves on at least 97 % of the rays."""
+    c = lc_case(name)
+    pol = lc.DPOptimizedPolicy(_device(c), int(c["pts_per_cam_ray"]))
+    got = pol.get_design_points(c["confidence_map"])
+    want = c["design_points"]
+    assert got.shape == want.shape and got.dtype == np.float64
+    same = np.all(got == want, axis=1).mean()
+    ul = O.entropy_lookup(c["confidence_map"])
+    x, z = c["confidence_map"][:, :, 0], c["confidence_map"][:, :, 1]
+
+    def merit(p):
+        return float(ul[O.interpolate_k(x, z, p[:, 0], p[:, 1])].astype(np.float64).sum())
+    assert abs(merit(got) - merit(want)) <= 1e-4 * max(1.0, abs(merit(want)))
+    assert same >= 0.97, same
+    # the device path from raw scores gives the same points, as a device tensor
+    pol.set_map_geometry(lc.confidence_grid(c["anchors"], int(c["K"]), *c["centres"].shape[:2],
+                                            c["wTc"]))
+    mask = None if c["mask"] is None else torch.from_numpy(c["mask"]).to(cuda)
+    dev = pol.design_points_from_scores(torch.from_numpy(c["cls"]).to(cuda), mask,
+                                        apply_sigmoid=False)
+    assert dev.is_cuda and np.array_equal(dev.cpu().numpy(), got)
+
+
+def test_dp_rejects_bad_arguments(cuda):
+    L = _lib.lib()
+    buf = torch.zeros(1 << 16, dtype=torch.uint8, device=cuda)
+    p = buf.data_ptr()
+    assert L.lcf_lc_dp_design(p, p, p, 4, 300, 0.2, p, p, buf.numel(), 0) == -3  # LCF_ERR_UNSUPPORTED
+    assert L.lcf_lc_dp_design(p, p, p, 4, 80, 0.2, p, p, 16, 0) == -2  # LCF_ERR_WORKSPACE
+    assert L.lcf_lc_dp_design(0, p, p, 4, 80, 0.2, p, p, buf.numel(), 0) == -1  # LCF_ERR_ARG
+    assert L.lcf_lc_entropy_lookup(p, 0, 4, 4, 0, 0, p, 0) == -1  # LCF_ERR_ARG
