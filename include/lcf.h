@@ -487,6 +487,22 @@ int lcf_nms(const float *dets, int n, int stride, int mode, float thresh, float 
             int inclusive, int max_keep, int *keep, int *num_keep, void *ws, size_t ws_bytes,
             void *stream);
 
+/* Incremental voxelisation of a growing cloud.  The light-curtain loop
+ * stacks every curtain's returns under the cumulative cloud and voxelises the whole cloud again on
+ * the host (second/light_curtain/utils.py:121-124 -> dataset._prep_func_main ->
+ * second/data/preprocess.py:626-639).  Here the cloud [n_capacity, f], the workspace
+ * (lcf_voxelize_workspace_bytes(n_capacity, max_pts)) and the four outputs stay resident on the
+ * device; a call voxelises only the points [n_begin, n_end) the caller has just written under the
+ * resident ones and leaves the outputs EQUAL to lcf_voxelize on points[0 .. n_end) from scratch
+ * (same voxel order, slots, counts and max_vox cut-off).  n_begin = 0 starts a session (the
+ * workspace is re-armed, rows beyond voxel_num zeroed); later calls must pass the previous call's
+ * n_end as n_begin and the same geometry arguments and buffers.  Point counts are host values. */
+int lcf_voxelize_append(const float *points, int n_capacity, int n_begin, int n_end, int f,
+                        const float vs[3], const float range[6], int max_pts, int max_vox,
+                        int cap_mode, int batch_idx, int coor_stride, float *voxels, int *coors,
+                        int *num_pts, int *voxel_num, void *ws, size_t ws_bytes, void *stream,
+                        lcf_ctx *ctx);
+
 /* ------------------------------------------------------------------------------------------
  * Light-curtain placement next to the detector: what LC_PROCESS
  * (second/light_curtain/utils.py:88-104) does on the host between two detector passes.

@@ -41,6 +41,9 @@ SYMBOLS = {
     "lcf_voxelize": (c_int, [c_void_p, c_int, c_void_p, c_int, _PF, _PF, c_int, c_int, c_int,
                              c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                              c_size_t, c_void_p, c_void_p]),
+    "lcf_voxelize_append": (c_int, [c_void_p, c_int, c_int, c_int, c_int, _PF, _PF, c_int, c_int,
+                                    c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                    c_void_p, c_size_t, c_void_p, c_void_p]),
     "lcf_voxelize_static_max_bytes": (c_size_t, []),
     "lcf_voxelize_static": (c_int, [c_void_p, c_int, c_void_p, c_int, _PF, _PF, c_int, c_int,
                                     c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
@@ -148,7 +151,7 @@ SYMBOLS = {
 
 # entry points whose LAST argument is the caller's lcf_ctx (NULL = defaults): the binding lets
 # Python callers omit it
-CTX_LAST = {"lcf_voxelize", "lcf_voxelize_workspace_reset", "lcf_rulebook_subm",
+CTX_LAST = {"lcf_voxelize", "lcf_voxelize_append", "lcf_voxelize_workspace_reset", "lcf_rulebook_subm",
             "lcf_rulebook_subm_workspace_reset", "lcf_rulebook_conv_workspace_reset",
             "lcf_rulebook_conv_discover", "lcf_rulebook_conv_fill", "lcf_indice_conv_fwd",
             "lcf_indice_conv_fwd_bf16", "lcf_indice_conv_fwd_bf16x3",

@@ -14,6 +14,13 @@
 //               whose id equals max_voxels marks where the sequential loop `break`s (i*).
 //   3. emit   : every kept point copies its row to voxels[vid][slot]; the first point of the cell
 //               also writes coors / num_points and zero-fills the unused slots.
+//
+// Appending (lcf_voxelize_append): the recipe is incremental as it stands.
+// The hash, the slot lists, cellslot / pvid and two counters (i*, number of first points so far)
+// stay in the workspace; a call for the points [n_begin, n_end) inserts only those (their indices
+// are larger than every resident one, so they queue behind them in the lists), scans first-flags
+// over those only on top of the resident count, and emits only those -- the first appended point
+// of a cell refreshes the cell's num_points.  The outputs equal a from-scratch run on [0, n_end).
 #include "common.h"
 
 #include <mutex>
@@ -29,12 +36,13 @@ struct VoxParams {
 };
 
 __global__ void __launch_bounds__(VOX_BLOCK)
-vox_insert_kernel(const float *__restrict__ pts, int n_cap, const int *__restrict__ n_dev, int f,
-                  VoxParams p, int max_pts, uint32_t *__restrict__ keys, uint32_t mask,
-                  int *__restrict__ lists, int *__restrict__ cellslot)
+vox_insert_kernel(const float *__restrict__ pts, int n_begin, int n_cap,
+                  const int *__restrict__ n_dev, int f, VoxParams p, int max_pts,
+                  uint32_t *__restrict__ keys, uint32_t mask, int *__restrict__ lists,
+                  int *__restrict__ cellslot)
 {
     const int n = lcf_count(n_cap, n_dev);
-    int i = blockIdx.x * VOX_BLOCK + threadIdx.x;
+    int i = n_begin + blockIdx.x * VOX_BLOCK + threadIdx.x;
     if (i >= n) return;
     int c[3];
     bool ok = true;
@@ -75,12 +83,12 @@ __device__ __forceinline__ int vox_is_first(const int *cellslot, const int *list
 
 __global__ void __launch_bounds__(VOX_BLOCK)
 vox_count_kernel(const int *__restrict__ cellslot, const int *__restrict__ lists, int max_pts,
-                 int n_cap, const int *__restrict__ n_dev, int *__restrict__ bsums,
+                 int n_begin, int n_cap, const int *__restrict__ n_dev, int *__restrict__ bsums,
                  int *__restrict__ ctrl)
 {
     __shared__ int lds[8];
     const int n = lcf_count(n_cap, n_dev);
-    int base = (blockIdx.x * VOX_BLOCK + threadIdx.x) * VOX_ITEMS;
+    int base = n_begin + (blockIdx.x * VOX_BLOCK + threadIdx.x) * VOX_ITEMS;
     int cnt = 0;
 #pragma unroll
     for (int j = 0; j < VOX_ITEMS; ++j) cnt += vox_is_first(cellslot, lists, max_pts, base + j, n);
@@ -88,24 +96,28 @@ vox_count_kernel(const int *__restrict__ cellslot, const int *__restrict__ lists
     lcf_block_excl_scan_256(cnt, lds, &total);
     if (threadIdx.x == 0) {
         bsums[blockIdx.x] = total;
-        if (blockIdx.x == 0) ctrl[0] = 0x7FFFFFFF; // i* = "never"
+        // ctrl[0] = i*, ctrl[1] = first points so far, ctrl[2] = that count before this call
+        if (blockIdx.x == 0) {
+            if (n_begin == 0) ctrl[0] = 0x7FFFFFFF; // i* = "never"
+            ctrl[2] = n_begin == 0 ? 0 : ctrl[1];
+        }
     }
 }
 
 __global__ void __launch_bounds__(VOX_BLOCK)
 vox_assign_kernel(const int *__restrict__ cellslot, const int *__restrict__ lists, int max_pts,
-                  int n_cap, const int *__restrict__ n_dev, const int *__restrict__ bsums,
-                  int max_vox, int *__restrict__ pvid, int *__restrict__ ctrl,
-                  int *__restrict__ voxel_num)
+                  int n_begin, int n_cap, const int *__restrict__ n_dev,
+                  const int *__restrict__ bsums, int max_vox, int *__restrict__ pvid,
+                  int *__restrict__ ctrl, int *__restrict__ voxel_num)
 {
     __shared__ int lds[8];
     const int n = lcf_count(n_cap, n_dev);
-    // prefix of the preceding blocks' sums
-    int part = 0;
+    // prefix of the preceding blocks' sums, on top of the first points of the earlier calls
+    int part = threadIdx.x == 0 ? ctrl[2] : 0;
     for (int b = threadIdx.x; b < (int)blockIdx.x; b += VOX_BLOCK) part += bsums[b];
     int blockbase;
     lcf_block_excl_scan_256(part, lds, &blockbase);
-    int base = (blockIdx.x * VOX_BLOCK + threadIdx.x) * VOX_ITEMS;
+    int base = n_begin + (blockIdx.x * VOX_BLOCK + threadIdx.x) * VOX_ITEMS;
     int fl[VOX_ITEMS];
     int cnt = 0;
 #pragma unroll
@@ -125,12 +137,14 @@ vox_assign_kernel(const int *__restrict__ cellslot, const int *__restrict__ list
     }
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
         int nfirst = blockbase + total;
+        ctrl[1] = nfirst;
         voxel_num[0] = nfirst < max_vox ? nfirst : max_vox;
     }
 }
 
 __global__ void __launch_bounds__(VOX_BLOCK)
-vox_emit_kernel(const float *__restrict__ pts, int n_cap, const int *__restrict__ n_dev, int f,
+vox_emit_kernel(const float *__restrict__ pts, int n_begin, int n_cap,
+                const int *__restrict__ n_dev, int f,
                 VoxParams p, int max_pts, int max_vox, int cap_mode, int batch_idx, int cstride,
                 const uint32_t *__restrict__ keys,
                 const int *__restrict__ lists, const int *__restrict__ cellslot,
@@ -140,13 +154,15 @@ vox_emit_kernel(const float *__restrict__ pts, int n_cap, const int *__restrict_
 {
     const int n = lcf_count(n_cap, n_dev);
     int i = blockIdx.x * VOX_BLOCK + threadIdx.x;
-    // (a) zero the rows beyond voxel_num (padded outputs of generate_multi_gpu)
-    if (i < max_vox && i >= voxel_num[0]) {
+    // (a) zero the rows beyond voxel_num (padded outputs of generate_multi_gpu); an appending
+    //     call finds them zero already
+    if (n_begin == 0 && i < max_vox && i >= voxel_num[0]) {
         float *row = voxels + (size_t)i * max_pts * f;
         for (int e = 0; e < max_pts * f; ++e) row[e] = 0.f;
         for (int e = 0; e < cstride; ++e) coors[i * cstride + e] = 0;
         num_pts[i] = 0;
     }
+    i += n_begin;
     if (i >= n) return;
     int h = cellslot[i];
     if (h < 0) return;
@@ -167,13 +183,16 @@ vox_emit_kernel(const float *__restrict__ pts, int n_cap, const int *__restrict_
     float *dst = voxels + ((size_t)vid * max_pts + slot) * f;
     const float *src = pts + (size_t)i * f;
     for (int e = 0; e < f; ++e) dst[e] = src[e];
-    if (slot == 0) {
+    // the first point of this call in its cell (= the cell's first point in a from-scratch
+    // call) owns the cell's count; the cell's first point also owns its coordinates and padding
+    if (slot == 0 || l[slot - 1] < n_begin) {
         int cnt = 0;
         for (int s = 0; s < max_pts; ++s) {
             int idx = l[s];
             if (idx != VOX_SENT && idx < istar) ++cnt;
         }
         num_pts[vid] = cnt;
+        if (slot != 0) return;
         float *row = voxels + (size_t)vid * max_pts * f;
         for (int e = cnt * f; e < max_pts * f; ++e) row[e] = 0.f;
         uint32_t key = keys[h];
@@ -243,11 +262,16 @@ extern "C" int lcf_voxelize_workspace_reset(void *ws, size_t ws_bytes, int n, in
     return vox_reset(w, max_pts, (hipStream_t)stream, ctx);
 }
 
+// Points [n_begin, n) of a cloud whose workspace is carved for n_carve points; n_begin = 0 is
+// the plain voxelizer.
 static int vox_run(const float *points, int n, const int *n_dev, int f, const float vs[3],
                    const float range[6], int max_pts, int max_vox, int cap_mode, int batch_idx,
                    int coor_stride, float *voxels, int *coors, int *num_pts, int *voxel_num,
-                   void *ws, size_t ws_bytes, bool reset, hipStream_t st)
+                   void *ws, size_t ws_bytes, bool reset, hipStream_t st, int n_begin = 0,
+                   int n_carve = -1, lcf_ctx *ctx = nullptr)
 {
+    if (n_carve < 0) n_carve = n;
+    if (n_begin < 0 || n_begin > n || n > n_carve) return LCF_ERR_ARG;
     if (n < 0 || f < 3 || max_pts <= 0 || max_vox <= 0 || !vs || !range || !voxels || !coors ||
         !num_pts || !voxel_num || !ws || (n > 0 && !points) || cap_mode < 0 || cap_mode > 1 ||
         (coor_stride != 3 && coor_stride != 4))
@@ -265,24 +289,29 @@ static int vox_run(const float *points, int n, const int *n_dev, int f, const fl
         cells *= (unsigned long long)p.grid[j];
     }
     if (cells >= 0xFFFFFFFFull) return LCF_ERR_RANGE;
-    VoxWs w = vox_carve(ws, n, max_pts);
+    VoxWs w = vox_carve(ws, n_carve, max_pts);
     if (ws_bytes < w.bytes) return LCF_ERR_WORKSPACE;
-    if (reset && vox_reset(w, max_pts, st) != LCF_OK) return LCF_ERR_LAUNCH;
-    if (n > 0) {
-        vox_insert_kernel<<<(n + VOX_BLOCK - 1) / VOX_BLOCK, VOX_BLOCK, 0, st>>>(
-            points, n, n_dev, f, p, max_pts, w.keys, w.hc - 1, w.lists, w.cellslot);
+    if (reset && vox_reset(w, max_pts, st, ctx) != LCF_OK) return LCF_ERR_LAUNCH;
+    const int n_new = n - n_begin;
+    int nblk = (n_new + VOX_BLOCK * VOX_ITEMS - 1) / (VOX_BLOCK * VOX_ITEMS);
+    if (nblk < 1) nblk = 1;
+    if (n_new > 0) {
+        vox_insert_kernel<<<(n_new + VOX_BLOCK - 1) / VOX_BLOCK, VOX_BLOCK, 0, st>>>(
+            points, n_begin, n, n_dev, f, p, max_pts, w.keys, w.hc - 1, w.lists, w.cellslot);
         LCF_CHECK_LAUNCH();
     }
-    vox_count_kernel<<<w.nblk, VOX_BLOCK, 0, st>>>(w.cellslot, w.lists, max_pts, n, n_dev,
-                                                   w.bsums, w.ctrl);
+    vox_count_kernel<<<nblk, VOX_BLOCK, 0, st>>>(w.cellslot, w.lists, max_pts, n_begin, n, n_dev,
+                                                 w.bsums, w.ctrl);
     LCF_CHECK_LAUNCH();
-    vox_assign_kernel<<<w.nblk, VOX_BLOCK, 0, st>>>(w.cellslot, w.lists, max_pts, n, n_dev,
-                                                    w.bsums, max_vox, w.pvid, w.ctrl, voxel_num);
+    vox_assign_kernel<<<nblk, VOX_BLOCK, 0, st>>>(w.cellslot, w.lists, max_pts, n_begin, n, n_dev,
+                                                  w.bsums, max_vox, w.pvid, w.ctrl, voxel_num);
     LCF_CHECK_LAUNCH();
-    int m = n > max_vox ? n : max_vox;
-    vox_emit_kernel<<<(m + VOX_BLOCK - 1) / VOX_BLOCK, VOX_BLOCK, 0, st>>>(
-        points, n, n_dev, f, p, max_pts, max_vox, cap_mode, batch_idx, coor_stride, w.keys, w.lists,
-        w.cellslot, w.pvid, w.ctrl, voxel_num, voxels, coors, num_pts);
+    int m = n_begin == 0 && max_vox > n_new ? max_vox : n_new;
+    if (m > 0) {
+        vox_emit_kernel<<<(m + VOX_BLOCK - 1) / VOX_BLOCK, VOX_BLOCK, 0, st>>>(
+            points, n_begin, n, n_dev, f, p, max_pts, max_vox, cap_mode, batch_idx, coor_stride,
+            w.keys, w.lists, w.cellslot, w.pvid, w.ctrl, voxel_num, voxels, coors, num_pts);
+    }
     LCF_CHECK_LAUNCH();
     return LCF_OK;
 }
@@ -297,6 +326,21 @@ extern "C" int lcf_voxelize(const float *points, int n, const int *n_dev, int f,
     return vox_run(points, n, n_dev, f, vs, range, max_pts, max_vox, cap_mode, batch_idx,
                    coor_stride, voxels, coors, num_pts, voxel_num, ws, ws_bytes, !ws_clean,
                    (hipStream_t)stream);
+}
+
+// Append the points [n_begin, n_end) of a resident cloud to a resident voxelisation (see the
+// header of this file).  n_begin == 0 starts a session: the workspace is re-armed first.
+extern "C" int lcf_voxelize_append(const float *points, int n_capacity, int n_begin, int n_end,
+                                   int f, const float vs[3], const float range[6], int max_pts,
+                                   int max_vox, int cap_mode, int batch_idx, int coor_stride,
+                                   float *voxels, int *coors, int *num_pts, int *voxel_num,
+                                   void *ws, size_t ws_bytes, void *stream, lcf_ctx *ctx)
+{
+    if (n_capacity < 0 || n_begin < 0 || n_end < n_begin || n_end > n_capacity) return LCF_ERR_ARG;
+    const bool ws_clean = ctx && ctx->o.ws_clean;
+    return vox_run(points, n_end, nullptr, f, vs, range, max_pts, max_vox, cap_mode, batch_idx,
+                   coor_stride, voxels, coors, num_pts, voxel_num, ws, ws_bytes,
+                   n_begin == 0 && !ws_clean, (hipStream_t)stream, n_begin, n_capacity, ctx);
 }
 
 // ---------------------------------------------------------------- the entry point that allocates

@@ -85,6 +85,72 @@ def voxelize(points, voxel_size, pc_range, max_points, max_voxels, cap_mode=0, n
     return voxels, coors, num, vnum
 
 
+class VoxelAccumulator:
+    """A cumulative point cloud and its voxelisation, both resident on the device (SURVEY.md 8f-2;
+    include/lcf.h: lcf_voxelize_append).  The light-curtain loop stacks each curtain's returns
+    under the cloud and voxelises everything again (second/light_curtain/utils.py:121-124);
+    ``append`` voxelises only the new points and leaves ``voxels / coors / num_points /
+    voxel_num`` equal to a from-scratch ``voxelize`` of the whole cloud.
+
+        acc = VoxelAccumulator(capacity, 4, voxel_size, pc_range, max_points, max_voxels)
+        acc.reset(); acc.append(lidar_points); ...; acc.append(curtain_points)
+        voxels, coors, num, vnum = acc.outputs            # device tensors, padded to max_voxels
+    """
+
+    def __init__(self, capacity, num_features, voxel_size, pc_range, max_points, max_voxels,
+                 cap_mode=0, batch_idx=None, device="cuda"):
+        dev = torch.device(device)
+        if dev.type != "cuda":
+            raise RuntimeError("objectdetection_amd ops need a GPU: no CPU path")
+        L = _lib.lib()
+        self.capacity, self.f = int(capacity), int(num_features)
+        self.voxel_size, self.pc_range = f3(voxel_size), f6(pc_range)
+        self.max_points, self.max_voxels = int(max_points), int(max_voxels)
+        self.cap_mode, self.batch_idx = int(cap_mode), batch_idx
+        self.cs = 3 if batch_idx is None else 4
+        self.points = torch.empty((self.capacity, self.f), dtype=torch.float32, device=dev)
+        self.voxels = torch.empty((self.max_voxels, self.max_points, self.f), dtype=torch.float32,
+                                  device=dev)
+        self.coors = torch.empty((self.max_voxels, self.cs), dtype=torch.int32, device=dev)
+        self.num = torch.empty((self.max_voxels,), dtype=torch.int32, device=dev)
+        self.vnum = torch.empty((1,), dtype=torch.int32, device=dev)
+        self.ws = _ws(L.lcf_voxelize_workspace_bytes(self.capacity, self.max_points), dev)
+        self.n = 0
+
+    def reset(self):
+        """Forget the cloud; the next append starts a new session."""
+        self.n = 0
+
+    @property
+    def outputs(self):
+        return self.voxels, self.coors, self.num, self.vnum
+
+    @property
+    def cloud(self):
+        return self.points[:self.n]
+
+    def append(self, new_points, ctx=None):
+        """new_points [M, F] float32 (device tensor, or host array: one H2D copy of the new rows
+        only).  Returns ``outputs``."""
+        if not torch.is_tensor(new_points):
+            new_points = torch.from_numpy(new_points)
+        if new_points.dim() != 2 or new_points.shape[1] != self.f or \
+                new_points.dtype != torch.float32:
+            raise ValueError("new_points must be [M,%d] float32" % self.f)
+        m = new_points.shape[0]
+        if self.n + m > self.capacity:
+            raise ValueError("cloud of %d points exceeds the accumulator's capacity %d"
+                             % (self.n + m, self.capacity))
+        self.points[self.n:self.n + m].copy_(new_points, non_blocking=True)
+        check(_lib.lib().lcf_voxelize_append(
+            _ptr(self.points), self.capacity, self.n, self.n + m, self.f, self.voxel_size,
+            self.pc_range, self.max_points, self.max_voxels, self.cap_mode,
+            int(self.batch_idx or 0), self.cs, _ptr(self.voxels), _ptr(self.coors),
+            _ptr(self.num), _ptr(self.vnum), _ptr(self.ws), self.ws.numel(), _stream(), ctx))
+        self.n += m
+        return self.outputs
+
+
 # ------------------------------------------------------------------ rulebooks
 
 def conv_out_shape(shape, ksize, stride, pad, dil):

@@ -127,6 +127,18 @@ class VoxelGeneratorV2:
         return {"voxels": voxels, "coordinates": coors, "num_points_per_voxel": num,
                 "voxel_num": vnum}
 
+    def accumulator(self, capacity, num_features=4, max_voxels=None, batch_idx=None):
+        """A device-resident cumulative cloud voxelised incrementally with this generator's
+        geometry (ops.VoxelAccumulator): for the light-curtain loop, which grows
+        the cloud by one curtain's returns per step (second/light_curtain/utils.py:121-124)."""
+        if self._full_mean:
+            raise NotImplementedError("full_mean rewrites the padding of every voxel; use "
+                                      "generate_device on the accumulator's cloud instead")
+        return ops.VoxelAccumulator(capacity, num_features, self._voxel_size,
+                                    self._point_cloud_range, self._max_num_points,
+                                    int(max_voxels or self._max_voxels), self._cap_mode,
+                                    batch_idx, self._dev())
+
     def _dev(self):
         if self._device is not None:
             return torch.device(self._device)
