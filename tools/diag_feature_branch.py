@@ -49,7 +49,14 @@ class FeatureOnly(FrameEngine):
                 coors, kd = l.out_coors, l.k_out
             self.ctx.set(_lib.OPT_CONV_ROWS_HINT, int(self.level_need[lvl]))
             last = l is self.layers[-1]
-            if l.x3:
+            if getattr(l, "planned", False):  # the plans of the previous full frame are resident
+                check(L.lcf_indice_conv_fwd_planned(
+                    P(feat), P(l.wimg), (3 if l.planes == 3 else 2) if l.x3 else 0,
+                    P(self.chain.plan[o.level]), self.chain.plan_rows[o.level], k_cap, P(k_dev),
+                    l.kvol, l.cin, l.cout, P(l.scale), P(l.shift), int(l.relu),
+                    P(self.dense if last else l.out), P(coors) if last else None, 1,
+                    i3(self.out_shape), st, cx))
+            elif l.x3:
                 fn = L.lcf_indice_conv_fwd_bf16x8 if l.planes == 3 else L.lcf_indice_conv_fwd_bf16x3
                 check(fn(P(feat), P(l.wimg), P(o.nbr), k_cap, P(k_dev), l.kvol, l.cin, l.cout,
                          P(l.scale), P(l.shift), int(l.relu), P(self.dense if last else l.out),
@@ -93,8 +100,27 @@ def main():
         out = eng.forward(c).clone()
         assert torch.equal(out, ref), "feature-only replay differs"
         feat = rate(eng, c)
+        # (c) both branches, but the feature branch does not WAIT for the rulebooks (it reads the
+        # identical ones the previous frame left): what remains above (b) is contention, what
+        # (a) has above (c) is waiting on the rulebook events
+        eng.feature_only = False
+        skip = {id(e) for e in eng.rb_events}
+        orig = torch.cuda.Stream.wait_event
+
+        def wait_event(self, ev):
+            if id(ev) not in skip:
+                orig(self, ev)
+        torch.cuda.Stream.wait_event = wait_event
+        try:
+            eng._capture()
+        finally:
+            torch.cuda.Stream.wait_event = orig
+        out = eng.forward(c).clone()
+        assert torch.equal(out, ref), "no-wait replay differs"
+        nowait = rate(eng, c)
     print(f"{cm}: two-branch frame {full:.1f} us, feature branch alone {feat:.1f} us, "
-          f"difference {full - feat:.1f} us")
+          f"difference {full - feat:.1f} us; both branches without rulebook waits {nowait:.1f} us "
+          f"(waiting {full - nowait:.1f} us, contention {nowait - feat:.1f} us)")
 
 
 if __name__ == "__main__":
