@@ -8,10 +8,19 @@ file:line each routine follows) plus numpy/torch restatements of the VFE
 (``oracle/vfe_oracle.py``, pinned by tests/golden/vfe_*.npz generated from the real
 /root/reference/second/pytorch/models/voxel_encoder.py).
 
-Parity pin status: voxelizer / rulebook / indice_conv are "parity unpinned" against the original
-numba / spconv binaries (absent, un-vendored, un-pinned: SURVEY.md F1, F2); they are pinned by
-known-answer tests and by equivalence with dense torch conv3d.  The VFE is pinned by golden
-vectors from the reference itself.
+Parity pin status (fixtures under tests/golden/, each made by running the reference's own files
+in the build container; generators committed beside them):
+  voxelizer      PINNED  voxel_golden.npz   <- second/utils/simplevis.py:8-59 (the in-tree twin of
+                         the missing points_to_voxel loop), run as plain Python
+  dense / gather PINNED  dense_golden.npz   <- torchplus/ops/array_ops.py:7-30
+  VFE            PINNED  vfe_golden.npz     <- second/pytorch/models/voxel_encoder.py
+  IoU / NMS      PINNED  nms_golden.npz     <- second/core/non_max_suppression/nms_gpu.py, its
+                         numba-CUDA kernels under a SIMT emulator (oracle/nms_oracle.py)
+  LC policy      PINNED  lc_policy_golden.npz <- second/light_curtain/policy.py, utils.py
+                         (oracle/lc_policy_oracle.py; the pylc device geometry alone is unpinned)
+  rulebook / indice_conv  "parity unpinned" against spconv's binaries (absent, un-vendored,
+                         version not pinned: SURVEY.md F2); pinned by known-answer tests and by
+                         equivalence with dense torch conv3d (tests/test_oracle_pins.py).
 """
 import ctypes
 import os
