@@ -2053,6 +2053,16 @@ extern "C" int lcf_indice_conv_wgrad_bf16(const float *feat, const float *dout,
     return LCF_ERR_UNSUPPORTED;
 }
 
+// cols columns of dout / dW[o] starting at the given pointers, rows ld floats apart
+static int cv_wgrad_cols(const float *feat, const float *dout, const int *in_nbr, int k_in, int kvol,
+                         int cin, int cols, int ld, float *dw, hipStream_t st)
+{
+    int CIN = cv_pad_cin(cin), COUT = cv_pad_cout(cols);
+    if (CIN < 0 || COUT < 0 || CIN * COUT > 8192) return LCF_ERR_UNSUPPORTED;
+    const int cout = cols;
+    CV_DISPATCH(cv_launch_wgrad, feat, dout, in_nbr, k_in, kvol, cin, cout, dw, st, cin, ld, ld);
+}
+
 extern "C" int lcf_indice_conv_wgrad(const float *feat, const float *dout, const int *in_nbr,
                                      int k_in, int kvol, int cin, int cout, float *dw,
                                      void *stream)
@@ -2062,11 +2072,19 @@ extern "C" int lcf_indice_conv_wgrad(const float *feat, const float *dout, const
         return LCF_ERR_ARG;
     if (kvol > LCF_MAX_KVOL) return LCF_ERR_UNSUPPORTED;
     int CIN = cv_pad_cin(cin), COUT = cv_pad_cout(cout);
-    if (CIN < 0 || COUT < 0 || CIN * COUT > 8192) return LCF_ERR_UNSUPPORTED;
+    if (CIN < 0 || COUT < 0) return LCF_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     if (lcf_fill32(dw, 0u, (size_t)kvol * cin * cout * 4, st) != LCF_OK) return LCF_ERR_LAUNCH;
     if (k_in == 0) return LCF_OK;
-    CV_DISPATCH(cv_launch_wgrad, feat, dout, in_nbr, k_in, kvol, cin, cout, dw, st);
+    if (CIN * COUT <= 8192) {
+        CV_DISPATCH(cv_launch_wgrad, feat, dout, in_nbr, k_in, kvol, cin, cout, dw, st);
+    }
+    // wider than one wave's accumulators (128 x 128): two column halves of dout and dW
+    if (cout & 1) return LCF_ERR_UNSUPPORTED;
+    const int h = cout / 2;
+    int rc = cv_wgrad_cols(feat, dout, in_nbr, k_in, kvol, cin, h, cout, dw, st);
+    if (rc != LCF_OK) return rc;
+    return cv_wgrad_cols(feat, dout + h, in_nbr, k_in, kvol, cin, h, cout, dw + h, st);
 }
 
 static int cv_linear_wgrad_block(const float *x, int ldx, const float *dy, int ldy, int n, int cin,

@@ -63,7 +63,8 @@ def test_forward_matches_oracle(oracle, cuda, cin, cout, subm):
 
 
 @pytest.mark.parametrize("cin,cout,subm", [(16, 32, False), (32, 32, True), (64, 64, True),
-                                           (4, 16, True), (128, 16, True), (5, 24, False)])
+                                           (4, 16, True), (128, 16, True), (5, 24, False),
+                                           (128, 128, True)])
 def test_backward_matches_oracle(oracle, cuda, cin, cout, subm):
     rng = np.random.default_rng(7 + cin)
     coors = _frame_coors(oracle, 1, 5000)
