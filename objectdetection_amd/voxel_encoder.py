@@ -216,7 +216,8 @@ class _VFEBase(nn.Module):
         xp = aug[:, t - 1, :]                                      # a padding row where wp > 0
         neg = torch.finfo(aug.dtype).min
         # relu(y * scale + shift) + per-voxel max and their backward as one kernel pair (liblcf)
-        fused = ops.affine_relu_segmax_supported(xr) and xr.shape[0] > 0
+        # (per layer: its channel count must suit the kernels; xr itself has 7 or 8 channels)
+        fused = xr.is_cuda and xr.dtype == torch.float32 and xr.shape[0] > 0
         vk32 = vk.int() if fused else None
         for i, vfe in enumerate(layers):
             yr = ops.tall_linear(vfe.linear, xr)
