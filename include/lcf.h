@@ -487,6 +487,34 @@ int lcf_nms(const float *dets, int n, int stride, int mode, float thresh, float 
             int inclusive, int max_keep, int *keep, int *num_keep, void *ws, size_t ws_bytes,
             void *stream);
 
+/* A VFE layer's tail in TRAINING mode over the real rows only: batch statistics, BatchNorm affine,
+ * ReLU, per-voxel maximum and the (pointwise | repeated) concatenation of
+ * second/pytorch/models/voxel_encoder.py:65-80 (VFELayer.forward) and :126-139 (the final Linear +
+ * norm + masked max), restated over the p rows that hold a point (the reference's [K, T, C]
+ * tensors are 78 % padding on a 20k-point frame; objectdetection_amd/voxel_encoder.py
+ * ::_forward_compact).  x [p, c] = Linear output of the real rows, seg [p] = voxel of each row,
+ * non-decreasing (a voxel's rows are contiguous) and every voxel 0..k-1 owning a row or not;
+ * n = K * T rows enter the statistics:
+ *   mode 0 (first layer): voxel v's padding rows are wp[v] copies of xp[v] (Linear output of its
+ *          padding representative): weight wp[v] in the statistics, once in the maximum;
+ *   mode 1 (later layer): padding rows are zeros: n - p zeros in the statistics, relu(shift) in
+ *          the maximum of every voxel with wp[v] > 0;
+ *   mode 2 (final Linear): statistics as mode 1, maxima start at 0.
+ * fwd: stats [5c] = scale | shift | mean | biased var | inv; modes 0 / 1: out [p, 2c] =
+ *   (relu(x * scale + shift) | agg[seg]) and agg [k, c]; mode 2: agg [k, c] is the result.
+ * bwd: gout = gradient of out [p, 2c] (modes 0 / 1) or of agg [k, c] (mode 2); dx [p, c], dxp [k, c]
+ *   (mode 0), dgamma / dbeta [c] -- gradients THROUGH the batch statistics included.
+ * c % 4 == 0, c <= 128.  ws: lcf_vfe_layer_workspace_bytes(p, k, c).  Deterministic. */
+size_t lcf_vfe_layer_workspace_bytes(int p, int k, int c);
+int lcf_vfe_layer_fwd(const float *x, int p, const float *xp, const float *wp, int k, int c,
+                      long long n, const int *seg, const float *gamma, const float *beta, float eps,
+                      int mode, float *out, float *agg, float *stats, void *ws, size_t ws_bytes,
+                      void *stream);
+int lcf_vfe_layer_bwd(const float *x, const float *agg, const float *gout, int p, const float *xp,
+                      const float *wp, int k, int c, long long n, const int *seg,
+                      const float *gamma, const float *stats, int mode, float *dx, float *dxp,
+                      float *dgamma, float *dbeta, void *ws, size_t ws_bytes, void *stream);
+
 /* Incremental voxelisation of a growing cloud.  The light-curtain loop
  * stacks every curtain's returns under the cumulative cloud and voxelises the whole cloud again on
  * the host (second/light_curtain/utils.py:121-124 -> dataset._prep_func_main ->

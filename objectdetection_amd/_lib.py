@@ -136,6 +136,15 @@ SYMBOLS = {
     "lcf_nms_workspace_bytes": (c_size_t, [c_int]),
     "lcf_nms": (c_int, [c_void_p, c_int, c_int, c_int, ctypes.c_float, ctypes.c_float, c_int,
                         c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "lcf_vfe_layer_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "lcf_vfe_layer_fwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int,
+                                  ctypes.c_longlong, c_void_p, c_void_p, c_void_p, ctypes.c_float,
+                                  c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
+                                  c_void_p]),
+    "lcf_vfe_layer_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int,
+                                  c_int, ctypes.c_longlong, c_void_p, c_void_p, c_void_p, c_int,
+                                  c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
+                                  c_void_p]),
     "lcf_lc_entropy_lookup": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p,
                                       c_void_p]),
     "lcf_lc_dp_workspace_bytes": (c_size_t, [c_int, c_int]),

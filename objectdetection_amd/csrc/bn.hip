@@ -412,3 +412,430 @@ extern "C" int lcf_vfe_affine_relu_segmax_bwd(const float *x, const float *y, co
     LCF_CHECK_LAUNCH();
     return LCF_OK;
 }
+
+// ------------------------------------------------------------------------------------------
+// A whole VFE layer tail in TRAINING mode over the real rows only (voxel_encoder.py:65-80 and
+// 126-139 as _forward_compact restates them): batch statistics over the n = K * T rows of the
+// reference's dense tensor, of which only the p real rows (and, first layer, one padding
+// representative per voxel with its multiplicity) are materialised; BatchNorm affine + ReLU;
+// per-voxel maximum including what the voxel's padding rows contribute.  One call forward, one
+// backward (was ~35 torch launches per layer and direction).
+//   mode 0 (first layer): the padding rows of voxel v are wp[v] copies of xp[v]: they enter the
+//           statistics with that weight and the maximum once, as relu(xp * scale + shift);
+//   mode 1 (later layer): padding rows are zeros (masked input, Linear without bias): n - p zeros
+//           in the statistics, relu(shift) in the maximum of every voxel with wp[v] > 0;
+//   mode 2 (final Linear): statistics as mode 1; the maximum starts at 0 (masked output >= 0).
+// Rows of one voxel are contiguous (seg non-decreasing): the first row of a run takes the run's
+// maximum in registers and writes agg[v] = max(init, run) with plain stores -- no atomics.
+#define VFE_NEG (-3.402823466e+38f)
+
+__global__ void __launch_bounds__(BN_BLOCK)
+vfe_wstats_kernel(const float *__restrict__ x, const float *__restrict__ w, int k, int c,
+                  int rows_per_block, float *__restrict__ parts)
+{
+    __shared__ __align__(16) float lds[BN_BLOCK * 8];
+    const BnMap m = bn_map(c);
+    const int r0 = blockIdx.x * rows_per_block;
+    const int r1 = min(k, r0 + rows_per_block);
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f), q = s;
+    if (m.rl < m.RL) {
+        for (int r = r0 + m.rl; r < r1; r += m.RL) {
+            const float wv = w ? w[r] : 1.f;
+            if (wv == 0.f) continue;
+            const float4 v = reinterpret_cast<const float4 *>(x + (size_t)r * c)[m.c4];
+            s.x += wv * v.x; s.y += wv * v.y; s.z += wv * v.z; s.w += wv * v.w;
+            q.x += wv * v.x * v.x; q.y += wv * v.y * v.y;
+            q.z += wv * v.z * v.z; q.w += wv * v.w * v.w;
+        }
+    }
+    bn_block_reduce(m, c, s, q, lds, parts + (size_t)blockIdx.x * 2 * c);
+}
+
+// stats [5c] = scale | shift | mean | biased var | inv  (n rows in all)
+__global__ void __launch_bounds__(BN_MAX_C)
+vfe_coeffs_fwd_kernel(const double *__restrict__ sums, double n, int c,
+                      const float *__restrict__ gamma, const float *__restrict__ beta, float eps,
+                      float *__restrict__ stats)
+{
+    const int e = threadIdx.x;
+    if (e >= c) return;
+    const double mean = sums[e] / n;
+    double var = sums[c + e] / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float inv = (float)(1.0 / sqrt(var + (double)eps));
+    const float sc = (gamma ? gamma[e] : 1.f) * inv;
+    stats[e] = sc;
+    stats[c + e] = (beta ? beta[e] : 0.f) - (float)mean * sc;
+    stats[2 * c + e] = (float)mean;
+    stats[3 * c + e] = (float)var;
+    stats[4 * c + e] = inv;
+}
+
+__device__ __forceinline__ float4 vfe_affine_relu(float4 v, float4 a, float4 b)
+{
+#pragma clang fp contract(off)
+    const float4 t = make_float4(v.x * a.x, v.y * a.y, v.z * a.z, v.w * a.w);
+    return make_float4(fmaxf(t.x + b.x, 0.f), fmaxf(t.y + b.y, 0.f), fmaxf(t.z + b.z, 0.f),
+                       fmaxf(t.w + b.w, 0.f));
+}
+
+__device__ __forceinline__ float4 vfe_max4(float4 a, float4 b)
+{
+    return make_float4(fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z), fmaxf(a.w, b.w));
+}
+
+// what the padding rows of voxel v put into its maximum
+__device__ __forceinline__ float4 vfe_pad_value(int mode, const float *xp, const float *wp, int v,
+                                                int c, int c4, float4 a, float4 b)
+{
+    if (mode == 2) return make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!(wp[v] > 0.f)) return make_float4(VFE_NEG, VFE_NEG, VFE_NEG, VFE_NEG);
+    if (mode == 1) return make_float4(fmaxf(b.x, 0.f), fmaxf(b.y, 0.f), fmaxf(b.z, 0.f),
+                                      fmaxf(b.w, 0.f));
+    return vfe_affine_relu(reinterpret_cast<const float4 *>(xp + (size_t)v * c)[c4], a, b);
+}
+
+// agg[v] = the padding rows' contribution, for every voxel (also those without a real row)
+__global__ void __launch_bounds__(BN_BLOCK)
+vfe_init_kernel(const float *__restrict__ xp, const float *__restrict__ wp, int k, int c, int mode,
+                const float *__restrict__ stats, float *__restrict__ agg)
+{
+    const int c4n = c >> 2;
+    const long long t = (long long)blockIdx.x * BN_BLOCK + threadIdx.x;
+    if (t >= (long long)k * c4n) return;
+    const int v = (int)(t / c4n), c4 = (int)(t % c4n);
+    const float4 a = reinterpret_cast<const float4 *>(stats)[c4];
+    const float4 b = reinterpret_cast<const float4 *>(stats + c)[c4];
+    reinterpret_cast<float4 *>(agg + (size_t)v * c)[c4] =
+        vfe_pad_value(mode, xp, wp, v, c, c4, a, b);
+}
+
+__global__ void __launch_bounds__(BN_BLOCK)
+vfe_layer_fwd_kernel(const float *__restrict__ x, int p, int c, int rows_per_block,
+                     const float *__restrict__ stats, const int *__restrict__ seg,
+                     float *__restrict__ y, int ldy, float *__restrict__ agg)
+{
+    const BnMap m = bn_map(c);
+    if (m.rl >= m.RL) return;
+    const float4 a = reinterpret_cast<const float4 *>(stats)[m.c4];
+    const float4 b = reinterpret_cast<const float4 *>(stats + c)[m.c4];
+    const int r0 = blockIdx.x * rows_per_block;
+    const int r1 = min(p, r0 + rows_per_block);
+    for (int r = r0 + m.rl; r < r1; r += m.RL) {
+        const float4 v =
+            vfe_affine_relu(reinterpret_cast<const float4 *>(x + (size_t)r * c)[m.c4], a, b);
+        if (y) reinterpret_cast<float4 *>(y + (size_t)r * ldy)[m.c4] = v;
+        const int sv = seg[r];
+        if (r == 0 || seg[r - 1] != sv) { // first row of the voxel's run: the run's maximum
+            float4 mx = v;
+            for (int r2 = r + 1; r2 < p && seg[r2] == sv; ++r2)
+                mx = vfe_max4(mx, vfe_affine_relu(
+                    reinterpret_cast<const float4 *>(x + (size_t)r2 * c)[m.c4], a, b));
+            float4 *d = reinterpret_cast<float4 *>(agg + (size_t)sv * c) + m.c4;
+            *d = vfe_max4(*d, mx); // one writer per (voxel, column group)
+        }
+    }
+}
+
+// g = [y > 0] * (gy + [y == agg[seg]] * gagg[seg]) with y recomputed; dx = g * scale; partial
+// sums of g and g * x
+__global__ void __launch_bounds__(BN_BLOCK)
+vfe_layer_bwd_kernel(const float *__restrict__ x, const float *__restrict__ agg,
+                     const float *__restrict__ gy, const float *__restrict__ gagg,
+                     const int *__restrict__ seg, int p, int c, int rows_per_block, int ldg,
+                     const float *__restrict__ stats, float *__restrict__ dx,
+                     float *__restrict__ parts)
+{
+    __shared__ __align__(16) float lds[BN_BLOCK * 8];
+    const BnMap m = bn_map(c);
+    const int r0 = blockIdx.x * rows_per_block;
+    const int r1 = min(p, r0 + rows_per_block);
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f), q = s;
+    if (m.rl < m.RL) {
+        const float4 a = reinterpret_cast<const float4 *>(stats)[m.c4];
+        const float4 b = reinterpret_cast<const float4 *>(stats + c)[m.c4];
+        for (int r = r0 + m.rl; r < r1; r += m.RL) {
+            const float4 xv = reinterpret_cast<const float4 *>(x + (size_t)r * c)[m.c4];
+            const float4 yv = vfe_affine_relu(xv, a, b);
+            const size_t so = (size_t)seg[r] * c;
+            const float4 av = reinterpret_cast<const float4 *>(agg + so)[m.c4];
+            const float4 ga = reinterpret_cast<const float4 *>(gagg + so)[m.c4];
+            float4 g = gy ? reinterpret_cast<const float4 *>(gy + (size_t)r * ldg)[m.c4]
+                          : make_float4(0.f, 0.f, 0.f, 0.f);
+            g.x = yv.x > 0.f ? g.x + (yv.x == av.x ? ga.x : 0.f) : 0.f;
+            g.y = yv.y > 0.f ? g.y + (yv.y == av.y ? ga.y : 0.f) : 0.f;
+            g.z = yv.z > 0.f ? g.z + (yv.z == av.z ? ga.z : 0.f) : 0.f;
+            g.w = yv.w > 0.f ? g.w + (yv.w == av.w ? ga.w : 0.f) : 0.f;
+            s.x += g.x; s.y += g.y; s.z += g.z; s.w += g.w;
+            q.x += g.x * xv.x; q.y += g.y * xv.y; q.z += g.z * xv.z; q.w += g.w * xv.w;
+            reinterpret_cast<float4 *>(dx + (size_t)r * c)[m.c4] =
+                make_float4(g.x * a.x, g.y * a.y, g.z * a.z, g.w * a.w);
+        }
+    }
+    bn_block_reduce(m, c, s, q, lds, parts + (size_t)blockIdx.x * 2 * c);
+}
+
+// out[r, c : 2c] = agg[seg[r]]: the "repeated" half of a VFE layer's output
+// (voxel_encoder.py:77-80)
+__global__ void __launch_bounds__(BN_BLOCK)
+vfe_repeat_kernel(const float *__restrict__ agg, const int *__restrict__ seg, int p, int c,
+                  float *__restrict__ out)
+{
+    const int c4n = c >> 2;
+    const long long t = (long long)blockIdx.x * BN_BLOCK + threadIdx.x;
+    if (t >= (long long)p * c4n) return;
+    const int r = (int)(t / c4n), c4 = (int)(t % c4n);
+    reinterpret_cast<float4 *>(out + (size_t)r * 2 * c + c)[c4] =
+        reinterpret_cast<const float4 *>(agg + (size_t)seg[r] * c)[c4];
+}
+
+// its backward: gagg[v] = sum over the voxel's run of rows of gout[r, c : 2c] (gagg zeroed
+// before; the first row of a run sums it in row order: deterministic, no atomics)
+__global__ void __launch_bounds__(BN_BLOCK)
+vfe_runsum_kernel(const float *__restrict__ gout, const int *__restrict__ seg, int p, int c,
+                  float *__restrict__ gagg)
+{
+    const int c4n = c >> 2;
+    const long long t = (long long)blockIdx.x * BN_BLOCK + threadIdx.x;
+    if (t >= (long long)p * c4n) return;
+    const int r = (int)(t / c4n), c4 = (int)(t % c4n);
+    const int sv = seg[r];
+    if (r != 0 && seg[r - 1] == sv) return;
+    float4 acc = reinterpret_cast<const float4 *>(gout + (size_t)r * 2 * c + c)[c4];
+    for (int r2 = r + 1; r2 < p && seg[r2] == sv; ++r2) {
+        const float4 v = reinterpret_cast<const float4 *>(gout + (size_t)r2 * 2 * c + c)[c4];
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    reinterpret_cast<float4 *>(gagg + (size_t)sv * c)[c4] = acc;
+}
+
+// the padding representatives' share of the same sums (modes 0 and 1); mode 0 also starts dxp
+__global__ void __launch_bounds__(BN_BLOCK)
+vfe_pad_bwd_kernel(const float *__restrict__ xp, const float *__restrict__ wp,
+                   const float *__restrict__ agg, const float *__restrict__ gagg, int k, int c,
+                   int rows_per_block, int mode, const float *__restrict__ stats,
+                   float *__restrict__ dxp, float *__restrict__ parts)
+{
+    __shared__ __align__(16) float lds[BN_BLOCK * 8];
+    const BnMap m = bn_map(c);
+    const int r0 = blockIdx.x * rows_per_block;
+    const int r1 = min(k, r0 + rows_per_block);
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f), q = s;
+    if (m.rl < m.RL) {
+        const float4 a = reinterpret_cast<const float4 *>(stats)[m.c4];
+        const float4 b = reinterpret_cast<const float4 *>(stats + c)[m.c4];
+        for (int v = r0 + m.rl; v < r1; v += m.RL) {
+            float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 xv = g;
+            if (wp[v] > 0.f) {
+                const float4 pv = vfe_pad_value(mode, xp, wp, v, c, m.c4, a, b);
+                const float4 av = reinterpret_cast<const float4 *>(agg + (size_t)v * c)[m.c4];
+                const float4 ga = reinterpret_cast<const float4 *>(gagg + (size_t)v * c)[m.c4];
+                g.x = pv.x > 0.f && pv.x == av.x ? ga.x : 0.f;
+                g.y = pv.y > 0.f && pv.y == av.y ? ga.y : 0.f;
+                g.z = pv.z > 0.f && pv.z == av.z ? ga.z : 0.f;
+                g.w = pv.w > 0.f && pv.w == av.w ? ga.w : 0.f;
+                if (mode == 0) xv = reinterpret_cast<const float4 *>(xp + (size_t)v * c)[m.c4];
+            }
+            s.x += g.x; s.y += g.y; s.z += g.z; s.w += g.w;
+            q.x += g.x * xv.x; q.y += g.y * xv.y; q.z += g.z * xv.z; q.w += g.w * xv.w;
+            if (dxp)
+                reinterpret_cast<float4 *>(dxp + (size_t)v * c)[m.c4] =
+                    make_float4(g.x * a.x, g.y * a.y, g.z * a.z, g.w * a.w);
+        }
+    }
+    bn_block_reduce(m, c, s, q, lds, parts + (size_t)blockIdx.x * 2 * c);
+}
+
+// sums [2c] = dshift | dscale  ->  dgamma, dbeta, and coef [2c] = A | B of the statistics' share
+// of the row gradients, dx += A * x + B:
+//   scale = gamma * inv, shift = beta - mean * scale, inv = (var + eps)^-1/2
+//   dgamma = inv * (dscale - mean * dshift), dbeta = dshift,
+//   dmean = -scale * dshift, dvar = -inv^3 / 2 * gamma * (dscale - mean * dshift),
+//   A = 2 dvar / n, B = dmean / n - A * mean
+__global__ void __launch_bounds__(BN_MAX_C)
+vfe_coeffs_bwd_kernel(const double *__restrict__ sums, double n, int c,
+                      const float *__restrict__ gamma, const float *__restrict__ stats,
+                      float *__restrict__ dgamma, float *__restrict__ dbeta,
+                      float *__restrict__ coef)
+{
+    const int e = threadIdx.x;
+    if (e >= c) return;
+    const double dshift = sums[e], dscale = sums[c + e];
+    const double mean = stats[2 * c + e], inv = stats[4 * c + e];
+    const double g = gamma ? gamma[e] : 1.0;
+    const double t = dscale - mean * dshift;
+    if (dgamma) dgamma[e] = (float)(inv * t);
+    if (dbeta) dbeta[e] = (float)dshift;
+    const double dmean = -(double)stats[e] * dshift;
+    const double dvar = -0.5 * inv * inv * inv * g * t;
+    const double A = 2.0 * dvar / n;
+    coef[e] = (float)A;
+    coef[c + e] = (float)(dmean / n - A * mean);
+}
+
+// dx[r] += w[r] * (A * x[r] + B)   (w NULL: 1)
+__global__ void __launch_bounds__(BN_BLOCK)
+vfe_axpb_kernel(const float *__restrict__ x, const float *__restrict__ w, int k, int c,
+                const float *__restrict__ coef, float *__restrict__ dx)
+{
+    const int c4n = c >> 2;
+    const long long t = (long long)blockIdx.x * BN_BLOCK + threadIdx.x;
+    if (t >= (long long)k * c4n) return;
+    const int r = (int)(t / c4n), c4 = (int)(t % c4n);
+    const float wv = w ? w[r] : 1.f;
+    if (wv == 0.f) return;
+    const float4 A = reinterpret_cast<const float4 *>(coef)[c4];
+    const float4 B = reinterpret_cast<const float4 *>(coef + c)[c4];
+    const float4 xv = reinterpret_cast<const float4 *>(x + (size_t)r * c)[c4];
+    float4 *d = reinterpret_cast<float4 *>(dx + (size_t)r * c) + c4;
+    float4 o = *d;
+    o.x += wv * (A.x * xv.x + B.x);
+    o.y += wv * (A.y * xv.y + B.y);
+    o.z += wv * (A.z * xv.z + B.z);
+    o.w += wv * (A.w * xv.w + B.w);
+    *d = o;
+}
+
+struct VfeLayerWs {
+    float *parts;  // [(np_rows + np_vox)][2c]
+    double *sums;  // [2c]
+    float *coef;   // [2c]
+    float *gagg;   // [k][c] (backward of modes 0 and 1)
+    int rpb_r, np_r, rpb_v, np_v;
+    size_t bytes;
+};
+
+static VfeLayerWs vfe_layer_carve(void *ws, int p, int k, int c)
+{
+    VfeLayerWs w;
+    bn_partition(p, &w.rpb_r, &w.np_r);
+    bn_partition(k, &w.rpb_v, &w.np_v);
+    char *b = (char *)ws;
+    size_t off = 0;
+    w.parts = (float *)(b + off);
+    off += lcf_align_up((size_t)(w.np_r + w.np_v) * 2 * c * sizeof(float), 256);
+    w.sums = (double *)(b + off);
+    off += lcf_align_up((size_t)2 * c * sizeof(double), 256);
+    w.coef = (float *)(b + off);
+    off += lcf_align_up((size_t)2 * c * sizeof(float), 256);
+    w.gagg = (float *)(b + off);
+    off += lcf_align_up((size_t)k * c * sizeof(float), 256);
+    w.bytes = off;
+    return w;
+}
+
+extern "C" size_t lcf_vfe_layer_workspace_bytes(int p, int k, int c)
+{
+    if (p <= 0 || k <= 0 || c <= 0) return 0;
+    return vfe_layer_carve(nullptr, p, k, c).bytes;
+}
+
+static int vfe_layer_check(const float *x, int p, const float *xp, const float *wp, int k, int c,
+                           long long n, const int *seg, int mode)
+{
+    int rc = bn_check(p, c);
+    if (rc) return rc;
+    if (k <= 0 || n < p || mode < 0 || mode > 2 || !x || !seg) return LCF_ERR_ARG;
+    if (mode != 2 && !wp) return LCF_ERR_ARG;
+    if (mode == 0 && !xp) return LCF_ERR_ARG;
+    if (((uintptr_t)x & 15) || ((uintptr_t)xp & 15)) return LCF_ERR_ARG;
+    return LCF_OK;
+}
+
+extern "C" int lcf_vfe_layer_fwd(const float *x, int p, const float *xp, const float *wp, int k,
+                                 int c, long long n, const int *seg, const float *gamma,
+                                 const float *beta, float eps, int mode, float *out, float *agg,
+                                 float *stats, void *ws, size_t ws_bytes, void *stream)
+{
+    int rc = vfe_layer_check(x, p, xp, wp, k, c, n, seg, mode);
+    if (rc) return rc;
+    if (!agg || !stats || !ws || (mode != 2 && !out) || ((uintptr_t)out & 15) ||
+        ((uintptr_t)agg & 15) || ((uintptr_t)stats & 15))
+        return LCF_ERR_ARG;
+    VfeLayerWs w = vfe_layer_carve(ws, p, k, c);
+    if (ws_bytes < w.bytes) return LCF_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    int np = w.np_r;
+    vfe_wstats_kernel<<<w.np_r, BN_BLOCK, 0, st>>>(x, nullptr, p, c, w.rpb_r, w.parts);
+    LCF_CHECK_LAUNCH();
+    if (mode == 0) {
+        vfe_wstats_kernel<<<w.np_v, BN_BLOCK, 0, st>>>(xp, wp, k, c, w.rpb_v,
+                                                       w.parts + (size_t)w.np_r * 2 * c);
+        LCF_CHECK_LAUNCH();
+        np += w.np_v;
+    }
+    bn_finalize_kernel<<<2 * c, 64, 0, st>>>(w.parts, np, 2 * c, w.sums);
+    LCF_CHECK_LAUNCH();
+    vfe_coeffs_fwd_kernel<<<1, BN_MAX_C, 0, st>>>(w.sums, (double)n, c, gamma, beta, eps, stats);
+    LCF_CHECK_LAUNCH();
+    const long long items = (long long)k * (c >> 2);
+    vfe_init_kernel<<<(unsigned)((items + BN_BLOCK - 1) / BN_BLOCK), BN_BLOCK, 0, st>>>(
+        xp, wp, k, c, mode, stats, agg);
+    LCF_CHECK_LAUNCH();
+    vfe_layer_fwd_kernel<<<w.np_r, BN_BLOCK, 0, st>>>(x, p, c, w.rpb_r, stats, seg,
+                                                      mode == 2 ? nullptr : out, 2 * c, agg);
+    LCF_CHECK_LAUNCH();
+    if (mode != 2) {
+        const long long ir = (long long)p * (c >> 2);
+        vfe_repeat_kernel<<<(unsigned)((ir + BN_BLOCK - 1) / BN_BLOCK), BN_BLOCK, 0, st>>>(
+            agg, seg, p, c, out);
+        LCF_CHECK_LAUNCH();
+    }
+    return LCF_OK;
+}
+
+extern "C" int lcf_vfe_layer_bwd(const float *x, const float *agg, const float *gout, int p,
+                                 const float *xp, const float *wp, int k, int c, long long n,
+                                 const int *seg, const float *gamma, const float *stats, int mode,
+                                 float *dx, float *dxp, float *dgamma, float *dbeta, void *ws,
+                                 size_t ws_bytes, void *stream)
+{
+    int rc = vfe_layer_check(x, p, xp, wp, k, c, n, seg, mode);
+    if (rc) return rc;
+    if (!agg || !gout || !stats || !dx || !ws || (mode == 0 && !dxp)) return LCF_ERR_ARG;
+    if (((uintptr_t)agg & 15) || ((uintptr_t)gout & 15) || ((uintptr_t)dx & 15) ||
+        ((uintptr_t)dxp & 15) || ((uintptr_t)stats & 15))
+        return LCF_ERR_ARG;
+    VfeLayerWs w = vfe_layer_carve(ws, p, k, c);
+    if (ws_bytes < w.bytes) return LCF_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    int np = w.np_r;
+    // modes 0 / 1: gout [p, 2c] = gradient of (y | agg[seg]); mode 2: gout [k, c] = gradient of agg
+    const float *gy = nullptr, *gagg = gout;
+    if (mode != 2) {
+        if (lcf_fill32(w.gagg, 0u, (size_t)k * c * 4, st) != LCF_OK) return LCF_ERR_LAUNCH;
+        const long long ir = (long long)p * (c >> 2);
+        vfe_runsum_kernel<<<(unsigned)((ir + BN_BLOCK - 1) / BN_BLOCK), BN_BLOCK, 0, st>>>(
+            gout, seg, p, c, w.gagg);
+        LCF_CHECK_LAUNCH();
+        gy = gout;
+        gagg = w.gagg;
+    }
+    vfe_layer_bwd_kernel<<<w.np_r, BN_BLOCK, 0, st>>>(x, agg, gy, gagg, seg, p, c, w.rpb_r, 2 * c,
+                                                      stats, dx, w.parts);
+    LCF_CHECK_LAUNCH();
+    if (mode != 2) {
+        vfe_pad_bwd_kernel<<<w.np_v, BN_BLOCK, 0, st>>>(xp, wp, agg, gagg, k, c, w.rpb_v, mode,
+                                                        stats, mode == 0 ? dxp : nullptr,
+                                                        w.parts + (size_t)w.np_r * 2 * c);
+        LCF_CHECK_LAUNCH();
+        np += w.np_v;
+    }
+    bn_finalize_kernel<<<2 * c, 64, 0, st>>>(w.parts, np, 2 * c, w.sums);
+    LCF_CHECK_LAUNCH();
+    vfe_coeffs_bwd_kernel<<<1, BN_MAX_C, 0, st>>>(w.sums, (double)n, c, gamma, stats, dgamma,
+                                                  dbeta, w.coef);
+    LCF_CHECK_LAUNCH();
+    const long long ir = (long long)p * (c >> 2);
+    vfe_axpb_kernel<<<(unsigned)((ir + BN_BLOCK - 1) / BN_BLOCK), BN_BLOCK, 0, st>>>(
+        x, nullptr, p, c, w.coef, dx);
+    LCF_CHECK_LAUNCH();
+    if (mode == 0) {
+        const long long iv = (long long)k * (c >> 2);
+        vfe_axpb_kernel<<<(unsigned)((iv + BN_BLOCK - 1) / BN_BLOCK), BN_BLOCK, 0, st>>>(
+            xp, wp, k, c, w.coef, dxp);
+        LCF_CHECK_LAUNCH();
+    }
+    return LCF_OK;
+}

@@ -870,6 +870,77 @@ def affine_relu_segmax(x, scale, shift, init, seg):
     return AffineReluSegMaxFunction.apply(x, scale, shift, init, seg)
 
 
+class VFELayerFunction(torch.autograd.Function):
+    """The tail of a VFE layer in training mode over the real rows only (include/lcf.h:
+    lcf_vfe_layer_fwd / _bwd): batch statistics with the padding rows in closed form, BatchNorm
+    affine, ReLU, per-voxel max and the (pointwise | repeated) concatenation -- one call each way,
+    gradients through the statistics included."""
+
+    @staticmethod
+    def forward(ctx, x, xp, wp, seg, gamma, beta, n, k, eps, mode):
+        x = x.contiguous()
+        p, c = x.shape
+        dev = x.device
+        L = _lib.lib()
+        if xp is not None:
+            xp = xp.contiguous()
+        agg = torch.empty((k, c), dtype=torch.float32, device=dev)
+        out = torch.empty((p, 2 * c), dtype=torch.float32, device=dev) if mode != 2 else None
+        stats = torch.empty((5 * c,), dtype=torch.float32, device=dev)
+        ws = _ws(L.lcf_vfe_layer_workspace_bytes(p, k, c), dev)
+        check(L.lcf_vfe_layer_fwd(_ptr(x), p, _ptr(xp), _ptr(wp), k, c, int(n), _ptr(seg),
+                                  _ptr(gamma), _ptr(beta), float(eps), int(mode), _ptr(out),
+                                  _ptr(agg), _ptr(stats), _ptr(ws), ws.numel(), _stream()))
+        ctx.save_for_backward(x, xp, wp, seg, gamma, agg, stats)
+        ctx.meta = (int(n), int(k), int(mode))
+        ctx.mark_non_differentiable(stats)
+        return (agg if mode == 2 else out), stats
+
+    @staticmethod
+    def backward(ctx, gout, _gstats):
+        x, xp, wp, seg, gamma, agg, stats = ctx.saved_tensors
+        n, k, mode = ctx.meta
+        p, c = x.shape
+        dev = x.device
+        L = _lib.lib()
+        gout = gout.contiguous()
+        dx = torch.empty_like(x)
+        dxp = torch.empty_like(xp) if mode == 0 else None
+        dgamma = torch.empty((c,), dtype=torch.float32, device=dev)
+        dbeta = torch.empty((c,), dtype=torch.float32, device=dev)
+        ws = _ws(L.lcf_vfe_layer_workspace_bytes(p, k, c), dev)
+        check(L.lcf_vfe_layer_bwd(_ptr(x), _ptr(agg), _ptr(gout), p, _ptr(xp), _ptr(wp), k, c, n,
+                                  _ptr(seg), _ptr(gamma), _ptr(stats), mode, _ptr(dx), _ptr(dxp),
+                                  _ptr(dgamma), _ptr(dbeta), _ptr(ws), ws.numel(), _stream()))
+        return dx, dxp, None, None, dgamma, dbeta, None, None, None, None
+
+
+def vfe_layer_supported(x, norm):
+    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.shape[0] > 0
+            and x.shape[1] % 4 == 0 and x.shape[1] <= 128
+            and isinstance(norm, torch.nn.BatchNorm1d) and norm.affine
+            and norm.weight.dtype == torch.float32)
+
+
+def vfe_layer_train(x, xp, wp, seg, norm, n, k, mode):
+    """x [p,c] Linear output of the real rows (xp [k,c]: of the padding representatives, mode 0),
+    wp [k] padding rows per voxel, seg [p] int32 sorted; nn.BatchNorm1d `norm` in training mode.
+    Returns the layer's output ([p,2c], or [k,c] for mode 2) and updates the running statistics
+    as nn.BatchNorm1d does."""
+    out, stats = VFELayerFunction.apply(x, xp, wp, seg, norm.weight, norm.bias, n, k, norm.eps,
+                                        mode)
+    if norm.track_running_stats:
+        with torch.no_grad():
+            c = x.shape[1]
+            norm.num_batches_tracked += 1
+            m = norm.momentum
+            if m is None:
+                m = 1.0 / float(norm.num_batches_tracked)
+            norm.running_mean.mul_(1 - m).add_(stats[2 * c:3 * c], alpha=m)
+            norm.running_var.mul_(1 - m).add_(stats[3 * c:4 * c], alpha=m * n / max(n - 1, 1))
+    return out
+
+
 def bn_relu_train(norm, x, relu=True):
     """nn.BatchNorm1d `norm` in training mode (+ ReLU) on x [K, C]: the fused kernels, then the
     running-statistics update nn.BatchNorm1d would have done (unbiased variance, momentum)."""

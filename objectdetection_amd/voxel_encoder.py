@@ -160,6 +160,7 @@ class _VFEBase(nn.Module):
         return torch.cat([features, features_relative], dim=-1)
 
     compact_training = True  # training forward over the real points only (_forward_compact)
+    fused_layer_training = True  # ... with each layer's tail as one liblcf call (lcf_vfe_layer_*)
 
     @staticmethod
     def _bn_rows(norm, xr, n, xp=None, wp=None):
@@ -219,9 +220,16 @@ class _VFEBase(nn.Module):
         # (per layer: its channel count must suit the kernels; xr itself has 7 or 8 channels)
         fused = xr.is_cuda and xr.dtype == torch.float32 and xr.shape[0] > 0
         vk32 = vk.int() if fused else None
+        layer_fused = fused and self.fused_layer_training
+        wp32 = wp.float().contiguous() if layer_fused else None
         for i, vfe in enumerate(layers):
             yr = ops.tall_linear(vfe.linear, xr)
             c = yr.shape[1]
+            if layer_fused and ops.vfe_layer_supported(yr, vfe.norm):
+                # statistics + affine + ReLU + max + concat and their backward: one call each way
+                yp = ops.tall_linear(vfe.linear, xp) if i == 0 else None
+                xr = ops.vfe_layer_train(yr, yp, wp32, vk32, vfe.norm, n, k, 0 if i == 0 else 1)
+                continue
             if i == 0:
                 yp = ops.tall_linear(vfe.linear, xp)
                 scale, shift = self._bn_rows(vfe.norm, yr, n, yp, wp)
@@ -237,6 +245,8 @@ class _VFEBase(nn.Module):
                 agg = _SegmentMax.apply(init, vk, yr)
             xr = torch.cat([yr, _SegmentGather.apply(agg, vk)], dim=1)
         yr = ops.tall_linear(self.linear, xr)
+        if layer_fused and ops.vfe_layer_supported(yr, self.norm):
+            return ops.vfe_layer_train(yr, None, wp32, vk32, self.norm, n, k, 2)
         scale, shift = self._bn_rows(self.norm, yr, n)
         out = torch.zeros((k, yr.shape[1]), dtype=yr.dtype, device=yr.device)
         if fused and yr.shape[1] % 4 == 0 and yr.shape[1] <= 128:
