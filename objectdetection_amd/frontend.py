@@ -47,7 +47,12 @@ class SparseFrontEnd(nn.Module):
         # every scene is enqueued first; the voxel counts come back in ONE synchronisation
         res = [self.voxel_generator.generate_device(pts, self.max_voxels, batch_idx=b)
                for b, pts in enumerate(clouds)]
-        ks = torch.cat([r["voxel_num"] for r in res]).tolist()
+        # (with them, the number of points kept: rows past voxel_num hold num_points = 0; the
+        # VFE's training path compacts the real rows without a synchronisation of its own)
+        kept = [r["num_points_per_voxel"].sum(dtype=torch.int32).view(1) for r in res]
+        counts = torch.cat([r["voxel_num"] for r in res] + kept).tolist()
+        ks = counts[:len(res)]
+        self.kept_points = int(sum(counts[len(res):]))
         vs = [r["voxels"][:k] for r, k in zip(res, ks)]
         ns = [r["num_points_per_voxel"][:k] for r, k in zip(res, ks)]
         cs = [r["coordinates"][:k] for r, k in zip(res, ks)]
@@ -65,7 +70,11 @@ class SparseFrontEnd(nn.Module):
 
     def forward(self, clouds):
         voxels, num_points, coors = self.voxelize(clouds)
-        feats = self.voxel_feature_extractor(voxels, num_points, coors)
+        self.voxel_feature_extractor.real_rows_hint = self.kept_points
+        try:
+            feats = self.voxel_feature_extractor(voxels, num_points, coors)
+        finally:
+            self.voxel_feature_extractor.real_rows_hint = None
         return self.middle_feature_extractor(feats, coors, len(clouds))
 
 

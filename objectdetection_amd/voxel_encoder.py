@@ -209,7 +209,13 @@ class _VFEBase(nn.Module):
         n = k * t
         aug = self._augment(features, num_voxels)
         mask = get_paddings_indicator(num_voxels, t, axis=0)
-        rows = mask.reshape(-1).nonzero(as_tuple=True)[0]          # flat ids of the real rows
+        hint = getattr(self, "real_rows_hint", None)
+        if hint is not None and hasattr(torch, "nonzero_static"):
+            # the caller knows how many rows hold a point (SparseFrontEnd reads it with the voxel
+            # counts): no host synchronisation here
+            rows = torch.nonzero_static(mask.reshape(-1), size=int(hint)).reshape(-1)
+        else:
+            rows = mask.reshape(-1).nonzero(as_tuple=True)[0]      # flat ids of the real rows
         vk = torch.div(rows, t, rounding_mode="floor")
         wp = (t - num_voxels.clamp(max=t)).to(aug.dtype)           # padding rows per voxel
         has_pad = (wp > 0).unsqueeze(1)
