@@ -14,6 +14,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "tc_plan.h"
 
 #include <mutex>
 #include <type_traits>
@@ -579,91 +580,7 @@ static size_t tc_lds_bytes(int CIN, int COUT, int TR, int kvol, bool bf16 = fals
 
 #define TC_THREADS(COUT) (((COUT) / 16 >= 4 ? 4 : (COUT) / 16) * 64)
 
-// The set-up of one tile of the tile-compacted kernels: neighbour tile -> LDS, rows per offset,
-// steps (= active offsets ascending), and the gather entries of every 16-row group.  Leaves, in
-// LDS: ent [items][16] ((input row << 7) | tile row; a group's padding entries gather a valid row
-// and point at the dump row), cnt / gbase [64] per offset, soff [64] per step, *nsteps_p.
-// Used by cv_tc_kernel (per launch) and by cv_plan_kernel (once per rulebook).
-template <int NWT, int TT>
-__device__ __forceinline__ void tc_build_steps(const int *__restrict__ nbr, int row0, int tr,
-                                               int kvol, int k_out, int *nl, unsigned *ent,
-                                               int *cnt, int *gbase, int *soff, int *nsteps_p,
-                                               int DUMP)
-{
-    const int tidw = threadIdx.x;
-    const int lane = tidw & 63;
-    const int wavew = __builtin_amdgcn_readfirstlane(tidw >> 6);
-    // ---- neighbour tile -> LDS (coalesced; rows past k_out read as -1)
-    {
-        const int total = tr * kvol;
-        const long long gbase_e = (long long)row0 * kvol;
-        const long long glimit = (long long)k_out * kvol;
-        for (int e = tidw; e < total; e += TT) {
-            int v = -1;
-            if (gbase_e + e < glimit) v = nbr ? nbr[gbase_e + e] : row0 + e; // NULL: identity
-            nl[e] = v;
-        }
-    }
-    __syncthreads();
-    // ---- rows per offset.  A wave takes offsets wavew, wavew + NWT, ...: the (up to MAXO) neighbour
-    //      ids of its lane's row are read once and kept, with their ballots, for the entry pass
-    //      below (the reads are independent: one LDS round trip, not one per offset)
-    constexpr int MAXO = (LCF_MAX_KVOL + NWT - 1) / NWT;
-    int idv[MAXO];
-#pragma unroll
-    for (int i = 0; i < MAXO; ++i) {
-        const int o = wavew + i * NWT;
-        idv[i] = (o < kvol && lane < tr) ? nl[lane * kvol + o] : -1;
-    }
-#pragma unroll
-    for (int i = 0; i < MAXO; ++i) {
-        const int o = wavew + i * NWT;
-        if (o < kvol) { // wave-uniform
-            const unsigned long long m = __ballot(idv[i] >= 0);
-            if (lane == 0) cnt[o] = __popcll(m);
-        }
-    }
-    __syncthreads();
-    // ---- steps = active offsets ascending; items = their 16-row groups
-    if (wavew == 0) {
-        const int c = lane < kvol ? cnt[lane] : 0;
-        const int ng = (c + 15) >> 4;
-        int incl = ng, sincl = c > 0 ? 1 : 0;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            int t = __shfl_up(incl, d, 64);
-            int u = __shfl_up(sincl, d, 64);
-            if (lane >= d) {
-                incl += t;
-                sincl += u;
-            }
-        }
-        gbase[lane] = incl - ng;
-        if (c > 0) soff[sincl - 1] = lane;
-        if (lane == 63) *nsteps_p = sincl;
-    }
-    __syncthreads();
-    // ---- item entries: (input row << 7 | output row of the tile); a group's padding entries
-    //      gather a valid row and dump the result
-#pragma unroll
-    for (int i = 0; i < MAXO; ++i) {
-        const int o = wavew + i * NWT;
-        if (o >= kvol) continue; // wave-uniform
-        const int id = idv[i];
-        const bool has = id >= 0;
-        const unsigned long long m = __ballot(has);
-        if (m == 0ull) continue;
-        const int c = __popcll(m);
-        const int p = __popcll(m & ((1ull << lane) - 1ull));
-        unsigned *dst = ent + gbase[o] * 16;
-        if (has) dst[p] = ((unsigned)id << 7) | (unsigned)lane;
-        const int first = __shfl(id, __builtin_ctzll(m), 64);
-        const int padded = ((c + 15) >> 4) << 4;
-        if (c + lane < padded) dst[c + lane] = ((unsigned)first << 7) | (unsigned)DUMP;
-    }
-    __syncthreads();
-}
-
+// (tc_build_steps: tc_plan.h, shared with rulebook_chain.hip)
 // BF16: operands rounded to bf16 (features when they enter LDS, weights in a bf16 image in
 // v_mfma_f32_16x16x32_bf16 fragment order), fp32 accumulation and fp32 output: the training
 // variant BASELINE.json configs[2] names.  Needs Cin a multiple of 32.
@@ -1070,7 +987,6 @@ cv_tc_kernel(const float *__restrict__ feat, const float *__restrict__ wimg,
 // indice_key, forward passes of later frames never: a plan belongs to one frame's rulebook).
 // One record per tile = the image of the kernel's LDS block: ent [32 * kvol] | cnt [64] |
 // gbase [64] | soff [64] | nsteps, padded to 16 bytes.
-static int tc_plan_stride(int kvol) { return (32 * kvol + 193 + 3) & ~3; }
 static int tc_tile_rows(int rows);
 
 __global__ void __launch_bounds__(256)
@@ -1095,6 +1011,7 @@ cv_plan_kernel(const int *__restrict__ nbr, int k_cap, const int *__restrict__ k
         cnt[threadIdx.x] = 0;
         gbase[threadIdx.x] = 0;
         soff[threadIdx.x] = 0;
+        if (threadIdx.x < 4) nsteps_p[threadIdx.x] = 0; // the count and the record's padding
     }
     __syncthreads();
     tc_build_steps<4, 256>(nbr, row0, tr, kvol, k_out, nl, ent, cnt, gbase, soff, nsteps_p, 32);
@@ -1128,7 +1045,7 @@ extern "C" int lcf_conv_tile_plan(const int *nbr, int k, const int *k_dev, int k
     if (k == 0) return LCF_OK;
     const int nb = (k + tile_rows - 1) / tile_rows;
     const int stride = tc_plan_stride(kvol);
-    const size_t lds = (size_t)(((32 * kvol + 3) & ~3) + stride + 4) * 4;
+    const size_t lds = tc_plan_lds_bytes(kvol);
     cv_plan_kernel<<<nb, 256, lds, (hipStream_t)stream>>>(nbr, k, k_dev, kvol, tile_rows, plan,
                                                           stride);
     LCF_CHECK_LAUNCH();

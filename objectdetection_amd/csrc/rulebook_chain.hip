@@ -16,19 +16,25 @@
 //   * the output table is sized by the OUTPUT capacity (2 x cap_out slots), not by the number of
 //     candidates (2 x k_in x E): 8-16x smaller, L2-resident; a table that fills up can only do so
 //     when the level overflows, which is reported; probing is bounded.
-// Launches for SpMiddleFHD: 2 + 3 per strided level = 14 (was 24 + 2 fills).
+//   * a level whose tile plan is wanted (lcf_rb_level.plan: the per-tile set-up of the
+//     tile-compacted convs, tc_plan.h) gets it from its look-up role: one workgroup per tile
+//     computes the tile's table rows, keeps them in LDS and writes the plan record -- no plan
+//     launch, no second read of the table (the stand-alone cv_plan_kernel remains for
+//     lcf_conv_tile_plan and LCF_OPT_RB_UNFUSED).
+// Launches for SpMiddleFHD: 2 + 3 per strided level = 14 (was 24 + 2 fills, + 6 plan launches).
 // Measured and NOT kept (tools/bench_chain.py, per-step kernel times): several independent items
 // per thread (fewer, longer waves: every step 30-60% slower -- a frame's tables are small enough
 // that all waves are resident at once, so more waves beat more chains per wave); a relaxed
 // agent-scope load in front of the CAS (inserts 9-16 -> 11-16 us); table entries rewritten as
 // key<<32|id by the assign step so that look-ups need one load (look-ups -10%, assign +40%).
 #include "rb_common.h"
+#include "tc_plan.h"
 
 #define RBC_MAX_ROLES 4
 #define RBC_PROBE_LIMIT 2048u
 #define RBC_NOFAIL 0xFFFFFFFFu
 
-enum { RBC_INS32 = 1, RBC_INS64, RBC_COUNT, RBC_ASSIGN, RBC_LOOKUP };
+enum { RBC_INS32 = 1, RBC_INS64, RBC_COUNT, RBC_ASSIGN, RBC_LOOKUP, RBC_LOOKUP_PLAN };
 
 struct RbcRole {
     int kind;
@@ -57,6 +63,9 @@ struct RbcRole {
     int lim_cap;
     const int *lim_dev;
     int *nbr;
+    // LOOKUP_PLAN: one workgroup per tile of plan_tr rows also writes the tile's plan record
+    int *plan;
+    int plan_tr, plan_stride;
 };
 
 struct RbcLaunch {
@@ -167,15 +176,10 @@ __device__ __forceinline__ void rbc_assign(const RbcRole &R, unsigned blk, unsig
     }
 }
 
-// thread (row n, offset o): the row of the previous level that feeds output n through offset o
+// (row n, offset o): the row of the previous level that feeds output n through offset o
 // (in = out * stride - pad + k * dil; a submanifold conv is stride 1, pad (k/2) * dil), or -1
-__device__ __forceinline__ void rbc_lookup(const RbcRole &R, unsigned blk)
+__device__ __forceinline__ int rbc_lookup_one(const RbcRole &R, int n, int o)
 {
-    const int k = lcf_count(R.k_cap, R.k_dev);
-    long long t = (long long)blk * RB_BLOCK + threadIdx.x;
-    if (t >= (long long)k * R.g.kvol) return;
-    int n = (int)(t / R.g.kvol);
-    int o = (int)(t - (long long)n * R.g.kvol);
     int4 c = reinterpret_cast<const int4 *>(R.coors)[n];
     int kx = o % R.g.ks[2];
     int ky = (o / R.g.ks[2]) % R.g.ks[1];
@@ -204,7 +208,56 @@ __device__ __forceinline__ void rbc_lookup(const RbcRole &R, unsigned blk)
             if (h != 0xFFFFFFFFu) res = R.vals32[h];
         }
     }
-    R.nbr[t] = res;
+    return res;
+}
+
+__device__ __forceinline__ void rbc_lookup(const RbcRole &R, unsigned blk)
+{
+    const int k = lcf_count(R.k_cap, R.k_dev);
+    long long t = (long long)blk * RB_BLOCK + threadIdx.x;
+    if (t >= (long long)k * R.g.kvol) return;
+    int n = (int)(t / R.g.kvol);
+    int o = (int)(t - (long long)n * R.g.kvol);
+    R.nbr[t] = rbc_lookup_one(R, n, o);
+}
+
+// The same table rows, one workgroup per TILE of plan_tr rows of the conv kernels, which then
+// builds the tile's plan record (tc_plan.h) from the neighbours it has just computed and still
+// holds in LDS: the plan costs no launch and no second read of the table.
+__device__ __forceinline__ void rbc_lookup_plan(const RbcRole &R, unsigned blk, unsigned char *smem)
+{
+    const int kvol = R.g.kvol, tr = R.plan_tr;
+    int *nl = reinterpret_cast<int *>(smem);                   // [32][kvol]
+    unsigned *ent = reinterpret_cast<unsigned *>(nl + ((32 * kvol + 3) & ~3));
+    int *cnt = reinterpret_cast<int *>(ent + 32 * kvol);
+    int *gbase = cnt + 64;
+    int *soff = gbase + 64;
+    int *nsteps_p = soff + 64;
+    const int k = lcf_count(R.k_cap, R.k_dev);
+    const int row0 = (int)blk * tr;
+    if (row0 >= k) return; // the conv kernels leave such a tile before reading its record
+    const int total = tr * kvol;
+    for (int e = threadIdx.x; e < total; e += RB_BLOCK) {
+        const int n = row0 + e / kvol;
+        int res = -1;
+        if (n < k) {
+            res = rbc_lookup_one(R, n, e % kvol);
+            R.nbr[(long long)row0 * kvol + e] = res;
+        }
+        nl[e] = res;
+    }
+    for (int e = threadIdx.x; e < 32 * kvol; e += RB_BLOCK) ent[e] = 0u; // unused entries: defined
+    if (threadIdx.x < 64) {
+        cnt[threadIdx.x] = 0;
+        gbase[threadIdx.x] = 0;
+        soff[threadIdx.x] = 0;
+        if (threadIdx.x < 4) nsteps_p[threadIdx.x] = 0; // the count and the record's padding
+    }
+    __syncthreads();
+    tc_build_steps_lds<4, RB_BLOCK>(tr, kvol, nl, ent, cnt, gbase, soff, nsteps_p, 32);
+    int4 *dst = reinterpret_cast<int4 *>(R.plan + (size_t)blk * R.plan_stride);
+    const int4 *src = reinterpret_cast<const int4 *>(ent);
+    for (int e = threadIdx.x; e < R.plan_stride / 4; e += RB_BLOCK) dst[e] = src[e];
 }
 
 // TAG only names the launch for profilers: 0 = level-0 table + first inserts, 1 = count (+ level-0
@@ -213,6 +266,7 @@ __device__ __forceinline__ void rbc_lookup(const RbcRole &R, unsigned blk)
 template <int TAG> __global__ void __launch_bounds__(RB_BLOCK) rbc_kernel(const RbcLaunch L)
 {
     __shared__ int lds[8];
+    extern __shared__ __align__(16) unsigned char rbc_smem[]; // plan-building roles only
     int i = 0;
 #pragma unroll
     for (int j = 1; j < RBC_MAX_ROLES; ++j)
@@ -226,6 +280,7 @@ template <int TAG> __global__ void __launch_bounds__(RB_BLOCK) rbc_kernel(const 
     case RBC_COUNT: rbc_count(R, blk, lds); break;
     case RBC_ASSIGN: rbc_assign(R, blk, nblk, lds); break;
     case RBC_LOOKUP: rbc_lookup(R, blk); break;
+    case RBC_LOOKUP_PLAN: rbc_lookup_plan(R, blk, rbc_smem); break;
     default: break;
     }
 }
@@ -300,7 +355,13 @@ static unsigned rbc_blocks(long long items)
 
 template <int TAG> static int rbc_launch_tag(const RbcLaunch &L, unsigned blocks, hipStream_t st)
 {
-    rbc_kernel<TAG><<<blocks, RB_BLOCK, 0, st>>>(L);
+    size_t lds = 0; // dynamic LDS: what the launch's plan-building roles need
+    for (int i = 0; i < L.n; ++i)
+        if (L.r[i].kind == RBC_LOOKUP_PLAN) {
+            const size_t b = tc_plan_lds_bytes(L.r[i].g.kvol);
+            lds = b > lds ? b : lds;
+        }
+    rbc_kernel<TAG><<<blocks, RB_BLOCK, lds, st>>>(L);
     LCF_CHECK_LAUNCH();
     return LCF_OK;
 }
@@ -321,6 +382,7 @@ static int rbc_launch(RbcLaunch &L, unsigned blocks, hipStream_t st, int tag, bo
             case RBC_INS64: rc = rbc_launch_tag<12>(one, nb, st); break;
             case RBC_COUNT: rc = rbc_launch_tag<13>(one, nb, st); break;
             case RBC_ASSIGN: rc = rbc_launch_tag<14>(one, nb, st); break;
+            case RBC_LOOKUP_PLAN: rc = rbc_launch_tag<16>(one, nb, st); break;
             default: rc = rbc_launch_tag<15>(one, nb, st); break;
             }
             if (rc) return rc;
@@ -399,6 +461,9 @@ extern "C" int lcf_rulebook_chain(const int *coors, int k, const int *k_dev, int
             if (rc) return rc;
             p.k_in_cap = cap;
             if (cap > 0 && !l.out_nbr) return LCF_ERR_ARG;
+            if (l.plan && (l.plan_tile_rows < 1 || l.plan_tile_rows > 32 ||
+                           ((uintptr_t)l.plan & 15)))
+                return LCF_ERR_ARG;
             if ((long long)cap * p.g.kvol >= 0x7FFFFFFFll) return LCF_ERR_RANGE;
             if (l.subm) continue;
             if (!l.ws || !l.k_out || !l.overflow || l.cap_out <= 0 || !l.out_coors)
@@ -428,8 +493,10 @@ extern "C" int lcf_rulebook_chain(const int *coors, int k, const int *k_dev, int
     cur.t64 = false;
     cur.prod = nullptr;
 
+    // a level whose tile plan is wanted gets it from its look-up role (unless LCF_OPT_RB_UNFUSED
+    // asks for the stand-alone kernels)
     auto add_lookup = [&](RbcLaunch &L, unsigned &blocks, const RbcCur &rows, const RbcCur &table,
-                          const RbcPlanLevel &p, int *nbr, bool strided) {
+                          const RbcPlanLevel &p, int *nbr, bool strided, const lcf_rb_level &lvl) {
         // rows: the level whose rows own the table being written; table: the level probed
         RbcRole &R = L.r[L.n++];
         R = RbcRole{};
@@ -453,7 +520,16 @@ extern "C" int lcf_rulebook_chain(const int *coors, int k, const int *k_dev, int
             R.mask32 = hc0 - 1;
         }
         R.nbr = nbr;
-        blocks += rbc_blocks((long long)rows.k_cap * p.g.kvol);
+        if (lvl.plan && !unfused) {
+            R.kind = RBC_LOOKUP_PLAN;
+            R.plan = lvl.plan;
+            R.plan_tr = lvl.plan_tile_rows;
+            R.plan_stride = tc_plan_stride(p.g.kvol);
+            const unsigned tiles = (unsigned)((rows.k_cap + R.plan_tr - 1) / R.plan_tr);
+            blocks += tiles < 1 ? 1u : tiles;
+        } else {
+            blocks += rbc_blocks((long long)rows.k_cap * p.g.kvol);
+        }
     };
     auto add_ins64 = [&](RbcLaunch &L, unsigned &blocks, const RbcCur &rows,
                          const RbcPlanLevel &p) {
@@ -485,7 +561,7 @@ extern "C" int lcf_rulebook_chain(const int *coors, int k, const int *k_dev, int
         }
     }
     auto record = [&](int i) -> int {
-        if (lv[i].plan) { // the conv kernels' per-tile set-up, once per rulebook
+        if (lv[i].plan && unfused) { // stand-alone plan kernel (fused into the look-ups otherwise)
             int rc = lcf_conv_tile_plan(lv[i].out_nbr, rows_cap[i], rows_dev[i], plan[i].g.kvol,
                                         lv[i].plan_tile_rows, lv[i].plan, stream);
             if (rc) return rc;
@@ -564,7 +640,7 @@ extern "C" int lcf_rulebook_chain(const int *coors, int k, const int *k_dev, int
                         L = RbcLaunch{};
                         blocks = 0;
                     }
-                    add_lookup(L, blocks, cur, cur, plan[i], lv[i].out_nbr, false);
+                    add_lookup(L, blocks, cur, cur, plan[i], lv[i].out_nbr, false, lv[i]);
                     ++i;
                 }
             }
@@ -610,10 +686,10 @@ extern "C" int lcf_rulebook_chain(const int *coors, int k, const int *k_dev, int
         {
             RbcLaunch L{};
             unsigned blocks = 0;
-            add_lookup(L, blocks, nxt, cur, plan[s], lv[s].out_nbr, true);
+            add_lookup(L, blocks, nxt, cur, plan[s], lv[s].out_nbr, true, lv[s]);
             int j = s + 1;
             while (j < s2 && L.n < RBC_MAX_ROLES - (s2 < n ? 1 : 0)) {
-                add_lookup(L, blocks, nxt, nxt, plan[j], lv[j].out_nbr, false);
+                add_lookup(L, blocks, nxt, nxt, plan[j], lv[j].out_nbr, false, lv[j]);
                 ++j;
             }
             if (s2 < n) add_ins64(L, blocks, nxt, plan[s2]);

@@ -154,3 +154,44 @@ def test_chain_empty_input(cuda):
     torch.cuda.synchronize()
     assert all(int(chain.k_out[i].item()) == 0 for i in chain.strided)
     assert chain.flags.tolist() == [0, 0, 0, 0]
+
+
+@pytest.mark.parametrize("device_count", [False, True])
+def test_plans_built_in_the_lookup_launches_equal_the_plan_kernel(cuda, device_count):
+    """lcf_rb_level.plan: the chain writes each wanted tile plan from the look-up role that
+    computes the tile's rows (tc_plan.h); lcf_conv_tile_plan builds it from the finished table.
+    Same records bit for bit for every tile that holds a row; also with the row count on the device
+    (capacity-sized launch) and with LCF_OPT_RB_UNFUSED (the stand-alone kernels)."""
+    from objectdetection_amd import _lib
+    pts = torch.from_numpy(synth.vkitti_frame(5, 20000)).to(cuda)
+    _, coors, _, vnum = ops.voxelize(pts, synth.VOXEL_SIZE, synth.PC_RANGE, 5, 40000, batch_idx=0)
+    k = int(vnum.item())
+    shape = [41, 1600, 1408]
+    plan_rows = {1: 25, 2: 32, 3: 17, 4: 32, 6: 20, 7: 32}
+    k_cap = 24000 if device_count else k
+    def build(unfused):
+        chain = ops.RulebookChain(FHD, k_cap, 1, shape, device=cuda, plan_rows=plan_rows)
+        ctx = _lib.Context()
+        ctx.set(_lib.OPT_RB_UNFUSED, int(unfused))
+        chain.run(coors[:k_cap].contiguous(), k_dev=vnum if device_count else None,
+                  ctx=ctx.handle)
+        torch.cuda.synchronize()
+        return chain
+    chain, ref_chain = build(False), build(True)
+    L = _lib.lib()
+    for i, tr in plan_rows.items():
+        rows = k if FHD[i]["subm"] and i == 0 else None
+        kd = chain.k_out[[j for j in range(i, -1, -1) if not FHD[j]["subm"]][0]]
+        n_rows = int(kd.item())
+        kvol = chain.kvol[i]
+        stride = len(chain.plan[i]) // max((chain.rows_cap[i] + tr - 1) // tr, 1)
+        tiles = (n_rows + tr - 1) // tr
+        want = torch.zeros_like(chain.plan[i])
+        _lib.check(L.lcf_conv_tile_plan(chain.out_nbr[i].data_ptr(), chain.rows_cap[i],
+                                        kd.data_ptr(), kvol, tr, want.data_ptr(),
+                                        torch.cuda.current_stream().cuda_stream))
+        torch.cuda.synchronize()
+        assert tiles > 10
+        assert torch.equal(chain.plan[i][:tiles * stride], want[:tiles * stride]), i
+        assert torch.equal(ref_chain.plan[i][:tiles * stride], want[:tiles * stride]), i
+        assert torch.equal(chain.out_nbr[i][:n_rows], ref_chain.out_nbr[i][:n_rows]), i
