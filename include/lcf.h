@@ -235,6 +235,19 @@ int lcf_rulebook_chain_reset(const lcf_rb_level *levels, int n, int k, void *ws0
 int lcf_rulebook_chain(const int *coors, int k, const int *k_dev, int batch, const int shape[3],
                        const lcf_rb_level *levels, int n, void *ws0, size_t ws0_bytes,
                        void *stream, lcf_ctx *ctx);
+/* The same walk enqueued in pieces, for a caller that interleaves it with the consumers of its
+ * tables on another stream (a graph executor may order a cross-stream wait behind everything that
+ * was enqueued on the producing stream before the wait, so enqueue only what the next consumer
+ * needs): part 0 = level-0 table, the submanifold tables of the input resolution, the first
+ * strided conv's inserts and count; part q >= 1 = ids, fill and submanifold tables of the q-th
+ * strided level (+ the next one's inserts and count).  lcf_rulebook_chain_num_parts = 1 + number
+ * of strided levels.  Call with the same arguments for every piece, parts in ascending order on
+ * one stream; part_first = 0 re-arms the workspaces (unless LCF_OPT_WS_CLEAN). */
+int lcf_rulebook_chain_num_parts(const lcf_rb_level *lv, int n);
+int lcf_rulebook_chain_parts(const int *coors, int k, const int *k_dev, int batch,
+                             const int shape[3], const lcf_rb_level *lv, int n, void *ws0,
+                             size_t ws0_bytes, int part_first, int part_last, void *stream,
+                             lcf_ctx *ctx);
 
 /* mirror a submanifold table: in_nbr[j][o] = out_nbr[j][kvol-1-o] */
 int lcf_rulebook_mirror(const int *nbr, int k, int kvol, int *mirrored, void *stream);

@@ -70,6 +70,10 @@ SYMBOLS = {
     "lcf_rulebook_chain": (c_int, [c_void_p, c_int, c_void_p, c_int, _PI3,
                                    ctypes.POINTER(RbLevel), c_int, c_void_p, c_size_t, c_void_p,
                                    c_void_p]),
+    "lcf_rulebook_chain_num_parts": (c_int, [ctypes.POINTER(RbLevel), c_int]),
+    "lcf_rulebook_chain_parts": (c_int, [c_void_p, c_int, c_void_p, c_int, _PI3,
+                                         ctypes.POINTER(RbLevel), c_int, c_void_p, c_size_t,
+                                         c_int, c_int, c_void_p, c_void_p]),
     "lcf_rulebook_mirror": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "lcf_rulebook_pairs_workspace_bytes": (c_size_t, [c_int, c_int]),
     "lcf_rulebook_pairs": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p,
@@ -165,7 +169,7 @@ CTX_LAST = {"lcf_voxelize", "lcf_voxelize_append", "lcf_voxelize_workspace_reset
             "lcf_rulebook_conv_discover", "lcf_rulebook_conv_fill", "lcf_indice_conv_fwd",
             "lcf_indice_conv_fwd_bf16", "lcf_indice_conv_fwd_bf16x3",
             "lcf_indice_conv_fwd_bf16x8", "lcf_indice_conv_fwd_dense", "lcf_fill_u32",
-            "lcf_rulebook_chain", "lcf_rulebook_chain_reset", "lcf_indice_conv_fwd_planned"}
+            "lcf_rulebook_chain", "lcf_rulebook_chain_parts", "lcf_rulebook_chain_reset", "lcf_indice_conv_fwd_planned"}
 
 
 class _Lib:

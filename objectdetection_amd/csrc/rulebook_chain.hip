@@ -438,13 +438,29 @@ extern "C" int lcf_rulebook_chain_reset(const lcf_rb_level *lv, int n, int k, vo
     return LCF_OK;
 }
 
-extern "C" int lcf_rulebook_chain(const int *coors, int k, const int *k_dev, int batch,
-                                  const int shape[3], const lcf_rb_level *lv, int n, void *ws0,
-                                  size_t ws0_bytes, void *stream, lcf_ctx *ctx)
+// Parts of the walk: part 0 = level-0 table, the first strided conv's inserts and count, the
+// submanifold look-ups of the input resolution; part q >= 1 = ids, fill and look-ups of the q-th
+// strided level, the next one's inserts and count.  Part q needs parts 0 .. q-1 enqueued before it
+// on the same stream.
+extern "C" int lcf_rulebook_chain_num_parts(const lcf_rb_level *lv, int n)
 {
-    if (!lv || n <= 0 || n > 64 || k < 0 || batch <= 0 || !shape || !ws0 || (k > 0 && !coors))
+    if (!lv || n <= 0) return 0;
+    int parts = 1;
+    for (int i = 0; i < n; ++i) parts += lv[i].subm ? 0 : 1;
+    return parts;
+}
+
+extern "C" int lcf_rulebook_chain_parts(const int *coors, int k, const int *k_dev, int batch,
+                                        const int shape[3], const lcf_rb_level *lv, int n,
+                                        void *ws0, size_t ws0_bytes, int part_first,
+                                        int part_last, void *stream, lcf_ctx *ctx)
+{
+    if (!lv || n <= 0 || n > 64 || k < 0 || batch <= 0 || !shape || !ws0 || (k > 0 && !coors) ||
+        part_first < 0 || part_last < part_first)
         return LCF_ERR_ARG;
     if (k >= (1 << 25)) return LCF_ERR_RANGE;
+    int part = 0; // the part the walk stands in; launches and records outside the range are skipped
+    auto on = [&]() { return part >= part_first && part <= part_last; };
     if (ws0_bytes < lcf_rulebook_subm_workspace_bytes(k)) return LCF_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     const bool unfused = ctx && ctx->o.rb_unfused;
@@ -480,7 +496,7 @@ extern "C" int lcf_rulebook_chain(const int *coors, int k, const int *k_dev, int
     const uint32_t hc0 = rb_capacity(k);
     uint32_t *keys0 = (uint32_t *)ws0;
     int *vals0 = (int *)((char *)ws0 + lcf_align_up((size_t)hc0 * 4, 256));
-    if (!(ctx && ctx->o.ws_clean)) {
+    if (!(ctx && ctx->o.ws_clean) && part_first == 0) {
         int rc = lcf_rulebook_chain_reset(lv, n, k, ws0, ws0_bytes, stream, nullptr);
         if (rc != LCF_OK) return rc;
     }
@@ -561,6 +577,7 @@ extern "C" int lcf_rulebook_chain(const int *coors, int k, const int *k_dev, int
         }
     }
     auto record = [&](int i) -> int {
+        if (!on()) return LCF_OK;
         if (lv[i].plan && unfused) { // stand-alone plan kernel (fused into the look-ups otherwise)
             int rc = lcf_conv_tile_plan(lv[i].out_nbr, rows_cap[i], rows_dev[i], plan[i].g.kvol,
                                         lv[i].plan_tile_rows, lv[i].plan, stream);
@@ -572,6 +589,7 @@ extern "C" int lcf_rulebook_chain(const int *coors, int k, const int *k_dev, int
         return LCF_OK;
     };
     if (k == 0) { // nothing to build: every strided level is empty
+        if (part_first > 0) return LCF_OK; // all of it was part 0
         for (int i = 0; i < n; ++i) {
             if (!lv[i].subm) {
                 if (lcf_fill32(lv[i].k_out, 0u, 4, st) != LCF_OK) return LCF_ERR_LAUNCH;
@@ -607,7 +625,7 @@ extern "C" int lcf_rulebook_chain(const int *coors, int k, const int *k_dev, int
         R.mask32 = hc0 - 1;
         blocks += rbc_blocks(k);
         if (s < n) add_ins64(L, blocks, cur, plan[s]);
-        int rc = rbc_launch(L, blocks, st, 0, unfused);
+        int rc = on() ? rbc_launch(L, blocks, st, 0, unfused) : LCF_OK;
         if (rc) return rc;
     }
     while (true) {
@@ -635,7 +653,7 @@ extern "C" int lcf_rulebook_chain(const int *coors, int k, const int *k_dev, int
                 // the fill launch)
                 while (i < s) {
                     if (L.n == RBC_MAX_ROLES) {
-                        int rc = rbc_launch(L, blocks, st, 1, unfused);
+                        int rc = on() ? rbc_launch(L, blocks, st, 1, unfused) : LCF_OK;
                         if (rc) return rc;
                         L = RbcLaunch{};
                         blocks = 0;
@@ -644,7 +662,7 @@ extern "C" int lcf_rulebook_chain(const int *coors, int k, const int *k_dev, int
                     ++i;
                 }
             }
-            int rc = rbc_launch(L, blocks, st, 1, unfused);
+            int rc = on() ? rbc_launch(L, blocks, st, 1, unfused) : LCF_OK;
             if (rc) return rc;
             for (int j = first_unrecorded; j < s; ++j) {
                 rc = record(j);
@@ -652,6 +670,8 @@ extern "C" int lcf_rulebook_chain(const int *coors, int k, const int *k_dev, int
             }
         }
         if (s >= n) break;
+        ++part;
+        if (part > part_last) break;
         // launch C: ids of the strided level (needs every block's count)
         {
             RbcLaunch L{};
@@ -670,7 +690,7 @@ extern "C" int lcf_rulebook_chain(const int *coors, int k, const int *k_dev, int
             R.out_coors = lv[s].out_coors;
             R.k_out = lv[s].k_out;
             R.overflow = lv[s].overflow;
-            int rc = rbc_launch(L, (unsigned)plan[s].w.nblk, st, 2, unfused);
+            int rc = on() ? rbc_launch(L, (unsigned)plan[s].w.nblk, st, 2, unfused) : LCF_OK;
             if (rc) return rc;
         }
         // launch X: fill of the strided level (probes the level it read), submanifold look-ups of
@@ -693,7 +713,7 @@ extern "C" int lcf_rulebook_chain(const int *coors, int k, const int *k_dev, int
                 ++j;
             }
             if (s2 < n) add_ins64(L, blocks, nxt, plan[s2]);
-            int rc = rbc_launch(L, blocks, st, 3, unfused);
+            int rc = on() ? rbc_launch(L, blocks, st, 3, unfused) : LCF_OK;
             if (rc) return rc;
             for (int q = s; q < j; ++q) {
                 rc = record(q);
@@ -705,4 +725,12 @@ extern "C" int lcf_rulebook_chain(const int *coors, int k, const int *k_dev, int
         s = s2;
     }
     return LCF_OK;
+}
+
+extern "C" int lcf_rulebook_chain(const int *coors, int k, const int *k_dev, int batch,
+                                  const int shape[3], const lcf_rb_level *lv, int n, void *ws0,
+                                  size_t ws0_bytes, void *stream, lcf_ctx *ctx)
+{
+    return lcf_rulebook_chain_parts(coors, k, k_dev, batch, shape, lv, n, ws0, ws0_bytes, 0,
+                                    0x7FFFFFFF, stream, ctx);
 }

@@ -333,38 +333,63 @@ class FrameEngine:
                              P(self.coors), P(self.num), P(self.vnum), P(self.vox_ws),
                              self.vox_ws.numel(), st, cx))
         kd = self.vnum
-        # ---- side stream: rulebook chain + clearing of the dense output
+        # ---- side stream: rulebook chain + clearing of the dense output.  The ORDER in which the
+        # two branches are enqueued matters to the graph executor of ROCm 7.2 (kernel traces of
+        # the replay): a node's cross-stream wait covers more of the
+        # producing stream than its edge says.  With the whole chain first the VFE starts 37 us
+        # after the voxelizer ends; with the VFE first it starts at once (+0.4 % frames/s).  The
+        # chain can also be enqueued in pieces (lcf_rulebook_chain_parts), each in front of the
+        # first conv that needs it: every join then costs ~10 us of cross-queue latency that the
+        # run-ahead chain hides (-1.5 %), so that is not the default.
         ready = {}
+        # LCF_ENGINE_ORDER: chain_first (whole chain, then the VFE), vfe_first (the VFE, then the
+        # whole chain), split0 (VFE, part 0, level-0 convs, rest of the chain), interleave
+        order = os.environ.get("LCF_ENGINE_ORDER", "vfe_first") if self.two_streams else "chain_first"
+        kd0 = kd
+        side_state = {"done": -1, "e_dense": None, "e_side": None}
+        last_part = self.chain.num_parts - 1
         if self.two_streams:
             ev = torch.cuda.Event()
             ev.record(main)
             side.wait_event(ev)
-        with torch.cuda.stream(side):
-            # every rulebook of the stack: one call, ~14 fused launches, an event per table
-            self.chain.run(self.coors, k_dev=kd, stream=sst, ctx=cx)
-            if self.two_streams:
-                for l in self.layers:
-                    if l.rb_owner is l:
-                        ready[id(l)] = self.rb_events[l.level]
+            for l in self.layers:
+                if l.rb_owner is l:
+                    ready[id(l)] = self.rb_events[l.level]
+
+        def side_tail():
             # the dense clear and the re-arming of the hash workspaces (for the next frame) as ONE
             # fill launch at the end of the branch
-            batch = os.environ.get("LCF_ENGINE_FILL_BATCH", "1") != "0"
-            if batch:
-                self.ctx.fill_batch_begin()
-            try:
-                check(L.lcf_fill_u32(P(self.dense), 0, self.dense.numel() * 4, sst, cx))
-                if self.two_streams and not batch:
-                    e_dense = torch.cuda.Event()
-                    e_dense.record(side)
-                self._reset_workspaces(sst)
-            finally:
+            with torch.cuda.stream(side):
+                batch = os.environ.get("LCF_ENGINE_FILL_BATCH", "1") != "0"
                 if batch:
-                    self.ctx.fill_batch_flush(sst)
-            if self.two_streams:
-                e_side = torch.cuda.Event()
-                e_side.record(side)
-                if batch:
-                    e_dense = e_side
+                    self.ctx.fill_batch_begin()
+                try:
+                    check(L.lcf_fill_u32(P(self.dense), 0, self.dense.numel() * 4, sst, cx))
+                    if self.two_streams and not batch:
+                        side_state["e_dense"] = torch.cuda.Event()
+                        side_state["e_dense"].record(side)
+                    self._reset_workspaces(sst)
+                finally:
+                    if batch:
+                        self.ctx.fill_batch_flush(sst)
+                if self.two_streams:
+                    side_state["e_side"] = torch.cuda.Event()
+                    side_state["e_side"].record(side)
+                    if batch:
+                        side_state["e_dense"] = side_state["e_side"]
+
+        def side_parts(upto):
+            if side_state["done"] >= upto:
+                return
+            with torch.cuda.stream(side):
+                self.chain.run(self.coors, k_dev=kd0, stream=sst, ctx=cx,
+                               parts=(side_state["done"] + 1, upto))
+            side_state["done"] = upto
+            if upto == last_part:
+                side_tail()
+
+        if order == "chain_first":
+            side_parts(last_part)
         # ---- main stream: features
         if self.vfe_kind == "vfe" and self.vfe_fused:
             (w1, c0, u1, s1, h1), (w2, _, u2, s2, h2), (w3, _, u3, s3, h3) = self.lin
@@ -386,13 +411,18 @@ class FrameEngine:
         else:
             check(L.lcf_vfe_mean(P(self.voxels), P(self.num), MV, P(kd), T, F,
                                  self.layers[0].cin, P(self.feat0), st))
+        if order == "vfe_first":
+            side_parts(last_part)
         feat, coors = self.feat0, self.coors
         waited = set()
         lvl = 0
         for l in self.layers:
             o = l.rb_owner
-            if self.two_streams and id(o) not in waited:
-                main.wait_event(ready[id(o)])
+            if id(o) not in waited:
+                need = self.chain.part_of_level[o.level]
+                side_parts(last_part if order == "split0" and need > 0 else need)
+                if self.two_streams:
+                    main.wait_event(ready[id(o)])
                 waited.add(id(o))
             if l.subm:
                 k_out_cap, k_out_dev = l.k_in_cap, kd
@@ -407,7 +437,8 @@ class FrameEngine:
             # dense() in the epilogue of the last conv: its rows go straight to [1,C,D,H,W]
             to_dense = l is self.layers[-1] and self.fuse_dense and l.cout in (16, 32, 64, 128)
             if to_dense and self.two_streams:
-                main.wait_event(e_dense)
+                side_parts(last_part)
+                main.wait_event(side_state["e_dense"])
             if l.planned:
                 lv = o.level
                 check(L.lcf_indice_conv_fwd_planned(
@@ -434,13 +465,14 @@ class FrameEngine:
                                             P(l.shift), int(l.relu), P(l.out), st, cx))
             feat = None if to_dense else l.out
         self.ctx.set(_lib.OPT_CONV_ROWS_HINT, 0)
+        side_parts(last_part)
         if feat is not None:
             if self.two_streams:
-                main.wait_event(e_dense)
+                main.wait_event(side_state["e_dense"])
             check(L.lcf_dense(P(feat), P(coors), feat.shape[0], P(kd), feat.shape[1], 1,
                               i3(self.out_shape), 0, P(self.dense), st))
         if self.two_streams:
-            main.wait_event(e_side)  # joins the side stream (its last operation)
+            main.wait_event(side_state["e_side"])  # joins the side stream (its last operation)
 
     def _capture(self):
         s = torch.cuda.Stream(device=self.dev)

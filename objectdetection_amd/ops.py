@@ -338,6 +338,12 @@ class RulebookChain:
                 self.plan_rows[i] = tr
                 lv.plan, lv.plan_tile_rows = self.plan[i].data_ptr(), tr
         self.ws0 = _ws(L.lcf_rulebook_subm_workspace_bytes(self.k_cap), dev)
+        # the part of the walk (lcf_rulebook_chain_parts) that completes each level's table
+        self.num_parts = L.lcf_rulebook_chain_num_parts(self.levels, self.n)
+        self.part_of_level, part = [], 0
+        for sp in specs:
+            part += 0 if sp["subm"] else 1
+            self.part_of_level.append(part)
 
     def set_event(self, i, event):
         """Record ``event`` (a torch.cuda.Event that has been recorded once, so that its handle
@@ -349,15 +355,17 @@ class RulebookChain:
                                               self.ws0.numel(),
                                               _stream() if stream is None else stream, ctx))
 
-    def run(self, indices, k_dev=None, stream=None, ctx=None):
-        """indices [k_cap (or fewer, without k_dev), 4] i32 cuda."""
+    def run(self, indices, k_dev=None, stream=None, ctx=None, parts=None):
+        """indices [k_cap (or fewer, without k_dev), 4] i32 cuda.  parts = (first, last): only
+        those pieces of the walk (``part_of_level``), for interleaving with the consumers."""
         k = self.k_cap if k_dev is not None else int(indices.shape[0])
         if k > self.k_cap:
             raise ValueError("rulebook chain: more rows than the planned capacity")
-        check(self.L.lcf_rulebook_chain(_ptr(indices), k, _ptr(k_dev), self.batch,
-                                        i3(self.shape), self.levels, self.n, _ptr(self.ws0),
-                                        self.ws0.numel(),
-                                        _stream() if stream is None else stream, ctx))
+        p0, p1 = (0, 0x7FFFFFFF) if parts is None else parts
+        check(self.L.lcf_rulebook_chain_parts(_ptr(indices), k, _ptr(k_dev), self.batch,
+                                              i3(self.shape), self.levels, self.n,
+                                              _ptr(self.ws0), self.ws0.numel(), int(p0), int(p1),
+                                              _stream() if stream is None else stream, ctx))
 
 
 # ------------------------------------------------------------------ indice_conv
