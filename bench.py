@@ -138,6 +138,78 @@ def cpu_baseline(model_name, cloud_np, budget_s, max_voxels=40000):
                       f"{threads} threads), not the original binaries"}
 
 
+def light_curtain_measurement(dev, cloud_np, with_cpu, reps=30):
+    """SURVEY.md 8f-2 / 8f-4, the two device-side pieces of the light-curtain loop around the
+    detector (second/light_curtain/utils.py:88-124): placing the curtain from the class scores
+    (entropy table + DPOptimizedPolicy's dynamic programme, 512 camera rays x 80 points on the
+    200 x 176 map) and voxelising the cloud grown by one curtain's returns.  HIP events; the numpy
+    oracle of the policy beside it on the host."""
+    from objectdetection_amd import light_curtain as lc, ops
+    cls_np, mask_np, anchors = synth.lc_scene(0)
+    geo = lc.LCGeometry()
+    pol = lc.DPOptimizedPolicy(geo, device=dev)
+    K, Y, X = cls_np.shape
+    xz = lc.confidence_grid(anchors, K, Y, X, geo.TRANSFORMS["wTc"])
+    pol.set_map_geometry(xz)
+    cls, mask = torch.from_numpy(cls_np).to(dev), torch.from_numpy(mask_np).to(dev)
+    e = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+
+    def timed(fn):
+        ts = []
+        for _ in range(reps + 3):
+            e[0].record()
+            fn()
+            e[1].record()
+            torch.cuda.synchronize()
+            ts.append(e[0].elapsed_time(e[1]))
+        return float(np.median(ts[3:]))
+    t_pol = timed(lambda: pol.design_points_from_scores(cls, mask, apply_sigmoid=False))
+    pts = pol.design_points_from_scores(cls, mask, apply_sigmoid=False)
+    rng = np.random.default_rng(1)
+    m = 3000
+    new = (cloud_np[rng.integers(0, len(cloud_np), m)] +
+           rng.normal(0, 0.05, (m, 4)).astype(np.float32)).astype(np.float32)
+    a_d, b_d = torch.from_numpy(cloud_np).to(dev), torch.from_numpy(new).to(dev)
+    acc = ops.VoxelAccumulator(len(cloud_np) + m, 4, synth.VOXEL_SIZE, synth.PC_RANGE, 5, 40000,
+                               device=dev)
+
+    def append():
+        acc.reset()
+        acc.append(a_d)
+        e[0].record()
+        acc.append(b_d)
+        e[1].record()
+        torch.cuda.synchronize()
+        return e[0].elapsed_time(e[1])
+    t_app = float(np.median([append() for _ in range(reps + 3)][3:]))
+    both = torch.cat([a_d, b_d])
+    t_full = timed(lambda: ops.voxelize(both, synth.VOXEL_SIZE, synth.PC_RANGE, 5, 40000))
+    out = {"policy": "DPOptimizedPolicy (entropy table + DP), scores resident on the device",
+           "map": [K, Y, X], "camera_rays": int(pts.shape[0]), "points_per_ray": 80,
+           "policy_ms": round(t_pol, 4),
+           "append_voxelize_us": round(t_app * 1e3, 1),
+           "from_scratch_voxelize_us": round(t_full * 1e3, 1),
+           "appended_points": m, "resident_points": int(len(cloud_np))}
+    if with_cpu:
+        from oracle import lc_policy_oracle as O  # the CPU restatement: baseline only
+        cam = geo.CAMERA_PARAMS
+        cmap = O.confidence_map(anchors, mask_np, cls_np, geo.TRANSFORMS["wTc"])
+        nodes, theta = O.build_graph(cmap[:, :, :2], cam, geo.TRANSFORMS["cTl"], 80)
+        k = nodes[:, :, 4].astype(np.int64)
+        ts = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            ul = O.entropy_lookup(O.confidence_map(anchors, mask_np, cls_np,
+                                                   geo.TRANSFORMS["wTc"]))
+            choice, _, _ = O.dp_design_vec(ul, k, theta, 14000 * 1.5e-5)
+            ts.append(time.perf_counter() - t0)
+        want = np.flip(nodes[np.arange(len(choice)), choice, :2], axis=0)
+        out["policy_cpu_ms"] = round(float(np.median(ts)) * 1e3, 2)
+        out["policy_cpu_kind"] = "port (numpy, 1 thread; the shape policy.py computes in)"
+        out["design_points_equal_cpu"] = float((pts.cpu().numpy() == want).all(axis=1).mean())
+    return out
+
+
 def train_measurement(args, dev, rank, world, dist, barrier):
     """BASELINE.json configs[2]/[3]: training step (VFE + sparse middle fwd/dgrad/wgrad + RPNV2 +
     loss + optimizer) on `train_batch` frames per rank, scene-sharded, ONE flat gradient
@@ -378,6 +450,9 @@ def main(argv=None):
             line["alt"] = alt
         if train is not None:
             line["train"] = train
+        if world == 1 and not args.eager and not args.no_alt:
+            line["light_curtain"] = light_curtain_measurement(dev, clouds_np[0],
+                                                              not args.no_cpu_baseline)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.model, clouds_np[0], args.cpu_budget,
                                                 args.max_voxels)

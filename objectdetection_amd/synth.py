@@ -95,3 +95,31 @@ def vkitti_frame(seed=0, n=20000):
 
 def synthia_frame(seed=0, n=120000):
     return _frame(seed, n, 640, 480, 39.32, 0.20, 0.70, 10)
+
+
+def lc_scene(seed, K=2, Y=200, X=176, bumps=12):
+    """A detector's class-score map for the light-curtain placement step: K anchor
+    types on the [Y, X] bird's-eye grid of the shipped configs (0.4 m cells over
+    [0, 70.4] x [-40, 40] m, base.yaml), scores in [0, 1] = a low floor plus a few Gaussian bumps;
+    an anchors mask that drops 10 % of the locations; anchor centres.  Returns (cls [K,Y,X] f32,
+    mask [K*Y*X] u8, anchors [K*Y*X, 7] f32)."""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:Y, 0:X].astype(np.float32)
+    cls = np.full((K, Y, X), 0.02, dtype=np.float32)
+    for k in range(K):
+        for _ in range(bumps):
+            cy, cx, sg = rng.uniform(0, Y), rng.uniform(0, X), rng.uniform(2.0, 8.0)
+            cls[k] += np.float32(rng.uniform(0.2, 0.9)) * np.exp(
+                -((yy - cy) ** 2 + (xx - cx) ** 2) / np.float32(2 * sg * sg))
+    cls = np.clip(cls, 0, 1).astype(np.float32)
+    mask = (rng.uniform(size=(K, Y, X)) < 0.9).reshape(-1).astype(np.uint8)
+    xs = (np.arange(X, dtype=np.float32) + 0.5) * np.float32(70.4 / X)
+    ys = (np.arange(Y, dtype=np.float32) + 0.5) * np.float32(80.0 / Y) - 40
+    anchors = np.zeros((K, Y, X, 7), dtype=np.float32)
+    anchors[..., 0] = xs[None, None, :]
+    anchors[..., 1] = ys[None, :, None]
+    anchors[..., 2] = -1.0
+    anchors[..., 3:6] = np.array([1.6, 3.9, 1.56], dtype=np.float32)
+    for k in range(K):
+        anchors[k, ..., 6] = np.float32(k * np.pi / K)
+    return cls, mask, anchors.reshape(-1, 7)
