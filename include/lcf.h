@@ -59,7 +59,8 @@ int lcf_version(void);
  *   by splitting its output columns: 1, 2 or 4; 0 = choose from the row count.
  * LCF_OPT_CONV_IMPL: forward kernel: 0 = per shape (tile-compacted when both channel counts are
  *   >= 32, split-slab for thin layers with <= 32 output channels, slab form for the rest),
- *   1 = slab form wherever it applies, 2 = tile-compacted, 3 = split-slab wherever it applies.
+ *   1 = slab form wherever it applies, 2 = tile-compacted, 3 = split-slab wherever it applies,
+ *   4 = thin-tile (compacted 64-row tiles) wherever it applies (<= 32 output channels).
  * LCF_OPT_CONV_TILE: output rows per workgroup of the tile-compacted forward: 16..32, or 0 = the
  *   largest height <= 32 that deals the tiles evenly over the 256 CUs.
  * LCF_OPT_CONV_SETS: wave sets per workgroup of the tile-compacted forward (a second set takes

@@ -516,6 +516,288 @@ static int cv_launch_ss(const float *feat, const float *wimg, const int *nbr, in
     return LCF_ERR_UNSUPPORTED;
 }
 
+// -------------------------------------------------------------------------- thin-tile fwd
+// The same thin layers (Cout <= 32), third form.  What bounds the split-slab kernel on 128 -> 16 is
+// neither its chain nor the gathers (splitting offsets instead of channels over the waves changes
+// nothing: 22.4 vs 22.8 us) but operands per useful row: a 16-row slab has 1.2 rows with a
+// neighbour at an average active offset, so every (slab, offset) item streams a whole W[o]
+// (8 KB at 128 x 16: ~190 MB of L2 traffic per launch) and runs full 16-row MFMAs for it.  Here a
+// workgroup owns a TILE of up to 64 output rows and compacts, per offset, the rows that have a
+// neighbour (as the tile-compacted kernel does): an item is 16 COMPACTED rows of one offset, W[o]
+// is fetched once per item of ~4x more useful rows, and the MFMA work drops by the same factor.
+// Items go round-robin to the four waves, each walking its items alone (operands straight into
+// the MFMA fragments, next item in flight behind this item's MFMAs); an item's 16 x Cout result
+// is added into the wave's OWN copy of the output tile in LDS, and the four copies are summed in
+// a fixed order at the end: deterministic, no atomics.
+// What it buys is modest (128 -> 16: 22.6 -> 19.9 us; 16 -> 32: 18.8 -> 15.4): the layer's 27
+// weight matrices (221 KB at 128 x 16) are larger than a tile's rows (32 KB), every tile needs
+// all of them, and an item still fetches its own W[o]: ~120 MB of L2 reads per launch instead of
+// ~190 MB.  The floor of any tile-owns-rows form is tiles x 221 KB.
+#define TN_TR 64
+template <int CIN, int COUT, int NW>
+__global__ void __launch_bounds__(NW * 64)
+cv_tn_kernel(const float *__restrict__ feat, const float *__restrict__ wimg,
+             const int *__restrict__ nbr, int k_cap, const int *__restrict__ k_dev, int kvol,
+             int cin, int cout, const float *__restrict__ scale,
+             const float *__restrict__ shift, int relu, float *__restrict__ out, int tr)
+{
+    const int k_out = lcf_count(k_cap, k_dev);
+    constexpr int KL = CIN / 4;               // k values per lane quarter (image convention)
+    constexpr int VW = KL < 4 ? KL : 4;
+    constexpr int SG = KL / VW;
+    constexpr int NT = COUT / 16;
+    constexpr int WELEMS = CIN * COUT;
+    constexpr int A4 = KL >= 4 ? KL / 4 : 1;
+    constexpr int OSTR = COUT + 1;            // output-tile row stride (floats)
+    constexpr int OTE = (TN_TR + 1) * OSTR;   // one wave's tile (+ the dump row of padding rows)
+    const int row0 = blockIdx.x * tr;
+    if (row0 >= k_out) return;
+
+    extern __shared__ __align__(16) unsigned char smem[];
+    float *ot = reinterpret_cast<float *>(smem);                       // [4][TN_TR + 1][OSTR]
+    int *nl = reinterpret_cast<int *>(ot + NW * OTE);            // [TN_TR][kvol]
+    unsigned *ent = reinterpret_cast<unsigned *>(nl + TN_TR * kvol);   // [kvol][TN_TR]
+    int *cnt = reinterpret_cast<int *>(ent + TN_TR * kvol);            // [64] rows per offset
+    int *ibase = cnt + 64;                                             // [64] first item of offset
+    int *nitems_p = ibase + 64;
+    int *iof = nitems_p + 4;                                           // [kvol * 4] offset of item
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r16 = lane & 15;
+    const int q = lane >> 4;
+    {
+        const int total = tr * kvol;
+        const long long gb = (long long)row0 * kvol, gl = (long long)k_out * kvol;
+        for (int e = tid; e < total; e += NW * 64) nl[e] = (gb + e < gl) ? nbr[gb + e] : -1;
+        for (int e = tid; e < NW * OTE; e += NW * 64) ot[e] = 0.f;
+    }
+    __syncthreads();
+    // ---- compaction: wave w takes offsets w, w + 4, ...; lane = tile row (tr <= 64)
+    for (int o = wave; o < kvol; o += NW) {
+        const int id = lane < tr ? nl[lane * kvol + o] : -1;
+        const unsigned long long m = __ballot(id >= 0);
+        const int c = __popcll(m);
+        if (id >= 0)
+            ent[o * TN_TR + __popcll(m & ((1ull << lane) - 1ull))] =
+                ((unsigned)id << 7) | (unsigned)lane;
+        if (lane == 0) cnt[o] = c;
+    }
+    __syncthreads();
+    if (wave == 0) { // items = 16-row groups, offsets ascending
+        const int c = lane < kvol ? cnt[lane] : 0;
+        const int ng = (c + 15) >> 4;
+        int incl = ng;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int t = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += t;
+        }
+        ibase[lane] = incl - ng;
+        for (int g = 0; g < ng; ++g) iof[incl - ng + g] = lane;
+        if (lane == 63) *nitems_p = incl;
+    }
+    __syncthreads();
+    const int nitems = __builtin_amdgcn_readfirstlane(*nitems_p);
+    float *myot = ot + wave * OTE;
+
+    const bool exact = (cin == CIN);
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    struct AFrag { float4 v[A4]; };
+    struct BFrag { float b[NT][KL]; };
+    // item -> (offset, group), wave-uniform
+    auto locate = [&](int it, int &o, int &g) {
+        o = __builtin_amdgcn_readfirstlane(iof[it]);
+        g = it - __builtin_amdgcn_readfirstlane(ibase[o]);
+    };
+    auto gather = [&](int o, int g, unsigned &e_out) -> AFrag {
+        AFrag a;
+        const int p = g * 16 + r16;
+        const bool has = p < cnt[o];
+        const unsigned e = has ? ent[o * TN_TR + p] : (unsigned)TN_TR; // padding: the dump row
+        e_out = e;
+#pragma unroll
+        for (int i = 0; i < A4; ++i) a.v[i] = zero4;
+        if (has) {
+            const float *src = feat + (size_t)(e >> 7) * cin + q * KL;
+            if (exact) {
+                if constexpr (KL >= 4) {
+#pragma unroll
+                    for (int i = 0; i < A4; ++i) a.v[i] = reinterpret_cast<const float4 *>(src)[i];
+                } else if constexpr (KL == 2) {
+                    const float2 x = *reinterpret_cast<const float2 *>(src);
+                    a.v[0].x = x.x;
+                    a.v[0].y = x.y;
+                } else {
+                    a.v[0].x = src[0];
+                }
+            } else {
+                float tmp[A4 * 4];
+#pragma unroll
+                for (int s = 0; s < A4 * 4; ++s)
+                    tmp[s] = (s < KL && q * KL + s < cin) ? src[s] : 0.f;
+#pragma unroll
+                for (int i = 0; i < A4; ++i)
+                    a.v[i] = make_float4(tmp[4 * i], tmp[4 * i + 1], tmp[4 * i + 2], tmp[4 * i + 3]);
+            }
+        }
+        return a;
+    };
+    auto bload = [&](int o) -> BFrag {
+        BFrag w;
+        const float *wo = wimg + (size_t)o * WELEMS;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            if constexpr (VW == 4) {
+#pragma unroll
+                for (int j = 0; j < KL / 4; ++j) {
+                    const float4 x = *reinterpret_cast<const float4 *>(
+                        wo + (((t * SG + j) * 4 + q) * 16 + r16) * 4);
+                    w.b[t][j * 4 + 0] = x.x;
+                    w.b[t][j * 4 + 1] = x.y;
+                    w.b[t][j * 4 + 2] = x.z;
+                    w.b[t][j * 4 + 3] = x.w;
+                }
+            } else if constexpr (VW == 2) {
+                const float2 x = *reinterpret_cast<const float2 *>(wo + ((t * 4 + q) * 16 + r16) * 2);
+                w.b[t][0] = x.x;
+                w.b[t][1] = x.y;
+            } else {
+                w.b[t][0] = wo[(t * 4 + q) * 16 + r16];
+            }
+        }
+        return w;
+    };
+    auto afloat = [&](const AFrag &a, int s) -> float {
+        const float4 x = a.v[s >> 2];
+        switch (s & 3) {
+        case 0: return x.x;
+        case 1: return x.y;
+        case 2: return x.z;
+        default: return x.w;
+        }
+    };
+
+    int it = wave;
+    if (it < nitems) {
+        int o, g;
+        locate(it, o, g);
+        unsigned ecur;
+        AFrag acur = gather(o, g, ecur);
+        BFrag bcur = bload(o);
+        for (;;) {
+            const int itn = it + NW;
+            const bool more = itn < nitems; // wave-uniform
+            AFrag an = acur;
+            BFrag bn = bcur;
+            unsigned en = ecur;
+            if (more) {
+                int on, gn;
+                locate(itn, on, gn);
+                an = gather(on, gn, en);
+                bn = bload(on);
+            }
+            f32x4 acc[NT][2];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                acc[t][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                acc[t][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int s = 0; s < KL; ++s)
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    acc[t][s & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                        afloat(acur, s), bcur.b[t][s], acc[t][s & 1], 0, 0, 0);
+            // C/D map: col = lane & 15, group row = q * 4 + reg -> the tile row of that entry
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const unsigned er = __shfl(ecur, q * 4 + r, 64); // entry of group row q*4+r
+                float *dst = myot + (er & 127u) * OSTR + r16;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) dst[t * 16] += acc[t][0][r] + acc[t][1][r];
+            }
+            if (!more) break;
+            it = itn;
+            acur = an;
+            bcur = bn;
+            ecur = en;
+        }
+    }
+    __syncthreads();
+    // ---- fixed-order sum of the waves' copies, (x*scale + shift), relu, coalesced store
+    for (int e = tid; e < tr * COUT; e += NW * 64) {
+        const int r = e / COUT, c = e % COUT;
+        const int row = row0 + r;
+        if (row < k_out && c < cout) {
+            const int a = r * OSTR + c;
+            float v = ot[a];
+#pragma unroll
+            for (int w = 1; w < NW; ++w) v += ot[w * OTE + a]; // fixed order
+            if (scale) v *= scale[c];
+            if (shift) v += shift[c];
+            if (relu) v = fmaxf(v, 0.f);
+            out[(size_t)row * cout + c] = v;
+        }
+    }
+}
+
+static size_t tn_lds_bytes(int COUT, int kvol, int nw)
+{
+    return (size_t)nw * (TN_TR + 1) * (COUT + 1) * 4 + (size_t)2 * TN_TR * kvol * 4 +
+           (size_t)(64 + 64 + 4 + 4 * kvol) * 4;
+}
+
+template <int CIN, int COUT, int NW>
+static int cv_launch_tn_n(const float *feat, const float *wimg, const int *nbr, int k_out,
+                          const int *k_dev, int kvol, int cin, int cout, const float *scale,
+                          const float *shift, int relu, float *out, hipStream_t st)
+{
+    const size_t lds = tn_lds_bytes(COUT, kvol, NW);
+    if (lds > 160 * 1024) return LCF_ERR_UNSUPPORTED;
+    {
+        static size_t lds_set = 0;
+        static std::mutex lds_mu;
+        std::lock_guard<std::mutex> lock(lds_mu);
+        if (lds > 64 * 1024 && lds > lds_set) {
+            if (hipFuncSetAttribute((const void *)cv_tn_kernel<CIN, COUT, NW>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lds) != hipSuccess)
+                return LCF_ERR_LAUNCH;
+            lds_set = lds;
+        }
+    }
+    const LcfOpts op = lcf_opts();
+    const int rows = op.rows_hint > 0 && op.rows_hint < k_out ? op.rows_hint : k_out;
+    // tile height: a whole number of tiles per CU where the launch is small
+    int tr = TN_TR;
+    const int m = (rows + 256 * TN_TR - 1) / (256 * TN_TR);
+    if (m >= 1) {
+        tr = (rows + 256 * m - 1) / (256 * m);
+        if (tr < 16) tr = 16;
+        if (tr > TN_TR) tr = TN_TR;
+    }
+    const int nb = (k_out + tr - 1) / tr;
+    cv_tn_kernel<CIN, COUT, NW><<<nb, NW * 64, lds, st>>>(feat, wimg, nbr, k_out, k_dev, kvol, cin,
+                                                        cout, scale, shift, relu, out, tr);
+    LCF_CHECK_LAUNCH();
+    return LCF_OK;
+}
+
+template <int CIN, int COUT>
+static int cv_launch_tn(const float *feat, const float *wimg, const int *nbr, int k_out,
+                        const int *k_dev, int kvol, int cin, int cout, const float *scale,
+                        const float *shift, int relu, float *out, hipStream_t st)
+{
+    if constexpr (COUT <= 32) {
+        // four waves: 8 and 16 waves per workgroup (shorter chains per wave, more private tiles)
+        // were measured and lose (128 -> 16: 19.9 / 22.5 / 83 us)
+        return cv_launch_tn_n<CIN, COUT, 4>(feat, wimg, nbr, k_out, k_dev, kvol, cin, cout, scale,
+                                            shift, relu, out, st);
+    }
+    return LCF_ERR_UNSUPPORTED;
+}
+
 // -------------------------------------------------------------------------- tile-compacted fwd
 // Second-generation forward ("tc"): the workgroup owns a tile of TR (32 or 64) output rows.
 // For every kernel offset it COMPACTS the rows of the tile that have a neighbour at that offset
@@ -1825,6 +2107,14 @@ extern "C" int lcf_indice_conv_fwd(const float *feat, const float *wimg, const i
     const bool slab_ok = nbr && CIN * COUT <= 8192;
     const bool use_slab = g_conv_impl == 1 ? slab_ok : (g_conv_impl == 2 ? false
                                                                         : slab_ok && (COUT < 32 || CIN < 32));
+    // thin layers, compacted 64-row tiles: only on request (LCF_OPT_CONV_IMPL = 4).  Alone they
+    // beat the split-slab form on two of the three SECOND layers (128 -> 16 19.9 vs 22.6 us,
+    // 16 -> 32 15.4 vs 18.8, 16 -> 16 9.5 vs 7.1), inside the frame -- beside the rulebook branch
+    // -- they lose (0.6977 vs 0.6936 ms per frame, A/B in one call, tools/ab_impl.py)
+    if (nbr && COUT <= 32 && g_conv_impl == 4) {
+        CV_DISPATCH(cv_launch_tn, feat, wimg, nbr, k_out, k_out_dev, kvol, cin, cout, scale,
+                    shift, relu, out, st);
+    }
     // thin layers: one 16-row slab per workgroup, waves split the reduction
     if (nbr && COUT <= 32 && (g_conv_impl == 3 || (g_conv_impl == 0 && (COUT < 32 || CIN < 32)))) {
         CV_DISPATCH(cv_launch_ss, feat, wimg, nbr, k_out, k_out_dev, kvol, cin, cout, scale,

@@ -62,6 +62,54 @@ def test_forward_matches_oracle(oracle, cuda, cin, cout, subm):
     assert rel_err(out2.cpu().numpy(), ref2) < RTOL
 
 
+@pytest.mark.parametrize("impl", [3, 4])
+@pytest.mark.parametrize("cin,cout,subm", [(128, 16, True), (16, 16, True), (16, 32, False),
+                                           (4, 16, True), (5, 24, False), (32, 32, True)])
+def test_thin_layer_forms_match_oracle(oracle, cuda, cin, cout, subm, impl):
+    """The split-slab (3) and thin-tile (4) forwards on the shapes they serve, pinned by
+    LCF_OPT_CONV_IMPL in a context: same results as the oracle, fused epilogue included, and
+    run-to-run bit-identical."""
+    from objectdetection_amd import _lib
+    rng = np.random.default_rng(cin * 7 + cout + impl)
+    coors = _frame_coors(oracle, 2, 9000)
+    extra = coors.copy()
+    extra[:, 3] = np.minimum(extra[:, 3] + 1, 1407)
+    coors = np.unique(np.concatenate([coors, extra[::3]], 0), axis=0)
+    rng.shuffle(coors, axis=0)
+    coors = np.ascontiguousarray(coors)
+    shape = [41, 1600, 1408]
+    k = coors.shape[0]
+    x = rng.standard_normal((k, cin)).astype(np.float32)
+    w = (rng.standard_normal((3, 3, 3, cin, cout)) / np.sqrt(27 * cin)).astype(np.float32)
+    if subm:
+        pairs, pn = oracle.rulebook_subm(coors, 1, shape, 3)
+        k_out = k
+    else:
+        oc, pairs, pn, _ = oracle.rulebook_conv(coors, 1, shape, 3, 2, 1)
+        k_out = oc.shape[0]
+    ref = oracle.indice_conv_fwd(x, w, pairs, pn, k_out)
+    rb = ops.build_rulebook(torch.from_numpy(coors).to(cuda), 1, shape, 3, 2, 1, 1, subm)
+    xt, wimg = torch.from_numpy(x).to(cuda), ops.weight_image(torch.from_numpy(w).to(cuda))
+    sc = torch.from_numpy(rng.uniform(0.5, 1.5, cout).astype(np.float32)).to(cuda)
+    sh = torch.from_numpy(rng.standard_normal(cout).astype(np.float32)).to(cuda)
+    ctx = _lib.Context()
+    ctx.set(_lib.OPT_CONV_IMPL, impl)
+    L = _lib.lib()
+
+    def run(scale, shift, relu):
+        out = torch.empty((k_out, cout), dtype=torch.float32, device=cuda)
+        P = lambda t: None if t is None else t.data_ptr()
+        _lib.check(L.lcf_indice_conv_fwd(P(xt), P(wimg), P(rb.out_nbr), k_out, None, 27, cin, cout,
+                                         P(scale), P(shift), int(relu), P(out),
+                                         torch.cuda.current_stream().cuda_stream, ctx.handle))
+        return out
+    a, b = run(None, None, False), run(None, None, False)
+    assert torch.equal(a, b)
+    assert rel_err(a.cpu().numpy(), ref) < RTOL
+    ref2 = np.maximum(ref * sc.cpu().numpy()[None] + sh.cpu().numpy()[None], 0)
+    assert rel_err(run(sc, sh, True).cpu().numpy(), ref2) < RTOL
+
+
 @pytest.mark.parametrize("cin,cout,subm", [(16, 32, False), (32, 32, True), (64, 64, True),
                                            (4, 16, True), (128, 16, True), (5, 24, False),
                                            (128, 128, True)])
@@ -552,7 +600,7 @@ def test_option_values_are_validated(cuda):
     assert L.lcf_set_option(_lib.OPT_CONV_TILE, 15) != 0
     assert L.lcf_set_option(_lib.OPT_CONV_TILE, 33) != 0
     assert L.lcf_set_option(_lib.OPT_CONV_SETS, 3) != 0
-    assert L.lcf_set_option(_lib.OPT_CONV_IMPL, 4) != 0
+    assert L.lcf_set_option(_lib.OPT_CONV_IMPL, 5) != 0
     assert L.lcf_set_option(99, 0) != 0
     # options that change what a call assumes about its buffers exist per context only
     assert L.lcf_set_option(_lib.OPT_WS_CLEAN, 1) != 0

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Runs the frame's three thin layers (128->16, 16->16, 16->32) on the split-slab kernel, 20 times
 each; meant for rocprofv3 --kernel-trace (tools/sum_tc_trace.py prints cv_ss durations too).
-LCF_LIB=<path> uses an experimental build."""
+LCF_LIB=<path> uses an experimental build; LCF_CONV_IMPL=3|4 pins the split-slab / thin-tile form."""
 import os
 import sys
 
@@ -15,6 +15,8 @@ from objectdetection_amd.spconv.modules import _bn_affine  # noqa: E402
 
 if os.environ.get("LCF_LIB"):
     _lib.LIB_PATH = os.path.abspath(os.environ["LCF_LIB"])
+if os.environ.get("LCF_CONV_IMPL"):
+    _lib.lib().lcf_set_option(_lib.OPT_CONV_IMPL, int(os.environ["LCF_CONV_IMPL"]))
 dev = torch.device("cuda:0")
 model = randomize_(SparseFrontEnd("M2").eval(), 0).to(dev)
 with torch.no_grad():
