@@ -17,6 +17,11 @@ run time, like the reference's expressions do: under NumPy >= 2 `theta * ones(fl
 float64, under the NumPy the reference was written for it was float32; cells on a rounding
 boundary can differ between the two.  The fixtures were generated under NumPy 2.2.
 
+All nine registered policies of policy.py exist under their names: DPOptimizedPolicy (entropy
+table + DP on the device), MaxEntropy / ParallelMaxEntropy (entropy table on the device, arg-max
+with torch), GreedyDPTiesRandom / GreedyDPTiesMinVel (entropy table on the device, the walk on the
+host), FixedParallel15/30/45 and RandomParallel (geometry only).
+
 `LCGeometry` carries the CAMERA_PARAMS / LASER_PARAMS / TRANSFORMS of pylc.LCDevice
 (pylc/pylc.py:29-146) for callers that have no pylc build; the light-curtain SIMULATOR
 (`get_return`) is outside SURVEY.md section 8 and is not provided.
@@ -258,3 +263,155 @@ class DPOptimizedPolicy(Policy):
         g = self.set_map_geometry(confidence_map[:, :, :2])
         choice = self._solve(self.confidence2entropy(confidence_map)).cpu().numpy()
         return np.flip(g["nodes"][np.arange(len(choice)), choice, :2], axis=0)
+
+
+class GreedyDP(DPOptimizedPolicy):
+    """policy.py:437-535: a forward greedy walk over the DP's graph -- the most uncertain allowed
+    successor of every ray, ties broken at random or by the smallest laser motion.  The entropy
+    table comes from the device kernel; the walk is T dependent steps over a handful of points
+    and runs on the host from the downloaded table (141 KB), as in the reference."""
+
+    def __init__(self, lc_device, pts_per_cam_ray=80, ties=None, debug=False, device="cuda"):
+        super().__init__(lc_device, pts_per_cam_ray, debug, device)
+        self._ties = ties
+
+    def _walk(self, ulookup):
+        g = self._graph
+        nodes, theta = g["nodes"], g["theta_las"]
+        k = nodes[:, :, 4].astype(np.int64)
+        r_unc = ulookup[k[0]]
+        cur = np.random.choice(np.where(r_unc == r_unc.max())[0])  # first point: random tie-break
+        trajectory = [nodes[0][[cur]]]
+        for t in range(1, len(nodes)):
+            d = theta[t] - theta[t - 1, cur]
+            neighbours = np.where((d < self._max_dtheta_las) & (d > -self._max_dtheta_las))[0]
+            if len(neighbours) == 0:
+                break  # the curtain cannot proceed any further
+            r_unc = ulookup[k[t][neighbours]]
+            keep = r_unc == r_unc.max()
+            neighbours, d_kept = neighbours[keep], d[neighbours][keep]
+            if self._ties == "random":
+                cur = np.random.choice(neighbours)
+            elif self._ties == "minvel":
+                cur = neighbours[np.argmin(np.abs(d_kept))]
+            else:
+                raise Exception("ties must be one of random/minvel")
+            trajectory.append(nodes[t][[cur]])
+        return np.flip(np.vstack(trajectory)[:, :2], axis=0)
+
+    def get_design_points(self, confidence_map):
+        confidence_map = np.asarray(confidence_map)
+        self.set_map_geometry(confidence_map[:, :, :2])
+        return self._walk(self.confidence2entropy(confidence_map).cpu().numpy())
+
+
+@register_lc_policy
+class GreedyDPTiesRandom(GreedyDP):
+    def __init__(self, lc_device, pts_per_cam_ray=80, debug=False, device="cuda"):
+        super().__init__(lc_device, pts_per_cam_ray, "random", debug, device)
+
+
+@register_lc_policy
+class GreedyDPTiesMinVel(GreedyDP):
+    def __init__(self, lc_device, pts_per_cam_ray=80, debug=False, device="cuda"):
+        super().__init__(lc_device, pts_per_cam_ray, "minvel", debug, device)
+
+
+def _parallel_lc_extent(lc_device, z):
+    """policy.py:548-557: the leftmost and rightmost x of the camera's field of view at depth z."""
+    x_max = z / np.tan(np.deg2rad(0.5 * lc_device.CAMERA_PARAMS["fov"]))
+    return -x_max, x_max
+
+
+def _parallel_curtain(lc_device, z):
+    x_min, x_max = _parallel_lc_extent(lc_device, z)
+    xs = np.linspace(x_min, x_max, 1600).reshape(-1, 1)
+    return np.hstack((xs, np.ones_like(xs) * z))
+
+
+class _HostPolicy(Policy):
+    """Policies that place a curtain without looking at the scores need no GPU."""
+
+    def __init__(self, lc_device, device=None):
+        self._lc_device = lc_device
+        self._dev = None
+
+
+@register_lc_policy
+class FixedParallel15(_HostPolicy):
+    def get_design_points(self, confidence_map):
+        return _parallel_curtain(self._lc_device, 15)
+
+
+@register_lc_policy
+class FixedParallel30(_HostPolicy):
+    def get_design_points(self, confidence_map):
+        return _parallel_curtain(self._lc_device, 30)
+
+
+@register_lc_policy
+class FixedParallel45(_HostPolicy):
+    def get_design_points(self, confidence_map):
+        return _parallel_curtain(self._lc_device, 45)
+
+
+@register_lc_policy
+class RandomParallel(_HostPolicy):
+    def get_design_points(self, confidence_map):
+        return _parallel_curtain(self._lc_device, np.random.uniform(5, 60))
+
+
+def _first_argmax(e, dim):
+    """Index of the first maximum along dim (numpy's argmax rule), on the device."""
+    n = e.shape[dim]
+    idx = torch.arange(n, device=e.device).view([-1 if d == dim else 1 for d in range(e.dim())])
+    top = e.max(dim=dim, keepdim=True).values
+    return torch.where(e == top, idx, n).min(dim=dim).values
+
+
+@register_lc_policy
+class MaxEntropy(Policy):
+    """policy.py:593-603: per camera-x row of the map, the cell of maximum entropy."""
+
+    def design_points_from_lookup(self, ulookup, xz):
+        X, Z = xz.shape[:2]
+        z_inds = _first_argmax(ulookup[1:].view(X, Z), 1).cpu().numpy()
+        return np.asarray(xz)[np.arange(X), z_inds]
+
+    def get_design_points(self, confidence_map):
+        confidence_map = np.asarray(confidence_map)
+        return self.design_points_from_lookup(self.confidence2entropy(confidence_map),
+                                              confidence_map[:, :, :2])
+
+
+@register_lc_policy
+class ParallelMaxEntropy(Policy):
+    """policy.py:605-673: a fronto-parallel curtain at the depth whose cells inside the camera's
+    field of view hold the most entropy, at least 5 m away."""
+
+    def __init__(self, lc_device, debug=False, device="cuda"):
+        super().__init__(lc_device, device)
+        self._fov_mask = {"cmap_wh": None, "mask": None}
+        self._debug = debug
+
+    def _create_fov_mask(self, xz):
+        theta = np.rad2deg(np.arctan2(xz[:, :, 1], xz[:, :, 0]))
+        fov = self._lc_device.CAMERA_PARAMS["fov"]
+        mask = (theta > 90 - 0.5 * fov) & (theta < 90 + 0.5 * fov)
+        return {"cmap_wh": tuple(xz.shape[:2]),
+                "mask": torch.from_numpy(np.ascontiguousarray(mask)).to(self._dev)}
+
+    def design_points_from_lookup(self, ulookup, xz):
+        xz = np.asarray(xz)
+        if self._fov_mask["cmap_wh"] != tuple(xz.shape[:2]):
+            self._fov_mask = self._create_fov_mask(xz)
+        X, Z = xz.shape[:2]
+        e = ulookup[1:].view(X, Z) * self._fov_mask["mask"]
+        z_max_entropy = max(xz[0, int(_first_argmax(e.sum(dim=0), 0)), 1], 5.0)
+        xs = xz[:, 0, [0]]
+        return np.hstack((xs, np.ones_like(xs) * z_max_entropy))
+
+    def get_design_points(self, confidence_map):
+        confidence_map = np.asarray(confidence_map)
+        return self.design_points_from_lookup(self.confidence2entropy(confidence_map),
+                                              confidence_map[:, :, :2])

@@ -191,3 +191,56 @@ def design_points(cmap, cam, cTl, pts_per_cam_ray=80, max_dtheta=14000 * 1.5e-5)
     choice, _, _ = dp_design(ul, nodes[:, :, 4].astype(np.int64), theta_las, max_dtheta)
     pts = nodes[np.arange(len(choice)), choice, :2]
     return np.flip(pts, axis=0)
+
+
+# ------------------------------------------------------------------ the other policies
+def parallel_extent(fov, z):
+    """policy.py:548-557."""
+    x_max = z / np.tan(np.deg2rad(0.5 * fov))
+    return -x_max, x_max
+
+
+def fixed_parallel(fov, z, n=1600):
+    """policy.py:560-591 (FixedParallel15/30/45) and :675-684 (RandomParallel, given its z)."""
+    x_min, x_max = parallel_extent(fov, z)
+    xs = np.linspace(x_min, x_max, n).reshape(-1, 1)
+    return np.hstack((xs, np.ones_like(xs) * z))
+
+
+def max_entropy(cmap):
+    """policy.py:593-603: per camera-x row, the cell of maximum entropy."""
+    e = entropy_lookup(cmap)[1:].reshape(cmap.shape[:2])
+    xz = cmap[:, :, :2]
+    return xz[np.arange(xz.shape[0]), np.argmax(e, axis=1)]
+
+
+def parallel_max_entropy(cmap, fov):
+    """policy.py:605-673: a fronto-parallel curtain at the depth of maximum summed entropy inside
+    the camera's field of view, at least 5 m away."""
+    x, z = cmap[:, :, 0], cmap[:, :, 1]
+    th = np.rad2deg(np.arctan2(z, x))
+    mask = (th > 90 - 0.5 * fov) & (th < 90 + 0.5 * fov)
+    e = entropy_lookup(cmap)[1:].reshape(cmap.shape[:2]) * mask
+    zc = max(cmap[0, np.argmax(e.sum(axis=0)), 1], 5.0)
+    xs = cmap[:, 0, [0]]
+    return np.hstack((xs, np.ones_like(xs) * zc))
+
+
+def greedy_dp(ulookup, nodes, theta_las, max_dtheta, ties, rng=np.random):
+    """policy.py:437-535 (GreedyDP): forward greedy walk over the DP's graph; ties "random"
+    (rng.choice, same call sequence as the reference) or "minvel"."""
+    k = nodes[:, :, 4].astype(np.int64)
+    r = ulookup[k[0]]
+    cur = rng.choice(np.where(r == r.max())[0])
+    traj = [nodes[0][[cur]]]
+    for t in range(1, len(nodes)):
+        d = theta_las[t] - theta_las[t - 1, cur]
+        nb = np.where((d < max_dtheta) & (d > -max_dtheta))[0]
+        if len(nb) == 0:
+            break
+        r = ulookup[k[t][nb]]
+        keep = r == r.max()
+        nb, dd = nb[keep], d[nb][keep]
+        cur = rng.choice(nb) if ties == "random" else nb[np.argmin(np.abs(dd))]
+        traj.append(nodes[t][[cur]])
+    return np.flip(np.vstack(traj)[:, :2], axis=0)

@@ -20,7 +20,8 @@ stored inputs.
 Per case the fixture holds: inputs (anchor centres [Y,X,3], sizes, anchors_mask, cls_preds,
 camera matrix/width/height, cTl, wTc, pts_per_cam_ray); the reference's confidence_map, its
 graph nodes [T,N,5], one row and one column of every edge's laser-angle differences, and the
-design points [T,2].
+design points [T,2]; and the design points of the other registered policies
+(`policy/<name>`; the random ones after `np.random.seed(77 + case index)`).
 """
 import importlib.util
 import os
@@ -151,6 +152,14 @@ def main():
         out[p + "dtheta_row0"] = drow
         out[p + "dtheta_col0"] = dcol
         out[p + "design_points"] = np.ascontiguousarray(dpts)
+        # the other registered policies (policy.py:437-684) on the same map and device
+        for pname in ("FixedParallel15", "FixedParallel30", "FixedParallel45", "MaxEntropy",
+                      "ParallelMaxEntropy", "RandomParallel", "GreedyDPTiesMinVel",
+                      "GreedyDPTiesRandom"):
+            cls_ = policy_mod.get_lc_policy_class(pname)
+            pol2 = cls_(dev, pts_per_cam_ray=N) if pname.startswith("GreedyDP") else cls_(dev)
+            np.random.seed(77 + ci)
+            out[p + "policy/" + pname] = np.ascontiguousarray(pol2.get_design_points(cmap))
         print(name, "cmap", cmap.shape, cmap.dtype, "nodes", nodes.shape, "design", dpts.shape,
               dpts.dtype, "distinct z:", len(np.unique(np.round(dpts[:, 1], 3))))
     out["cases"] = np.array(names)

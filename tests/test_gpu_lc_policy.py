@@ -135,3 +135,54 @@ def test_dp_rejects_bad_arguments(cuda):
     assert L.lcf_lc_dp_design(p, p, p, 4, 80, 0.2, p, p, 16, 0) == -2  # LCF_ERR_WORKSPACE
     assert L.lcf_lc_dp_design(0, p, p, 4, 80, 0.2, p, p, buf.numel(), 0) == -1  # LCF_ERR_ARG
     assert L.lcf_lc_entropy_lookup(p, 0, 4, 4, 0, 0, p, 0) == -1  # LCF_ERR_ARG
+
+
+@pytest.mark.parametrize("name", LC_CASES)
+def test_other_policies_against_reference_design_points(cuda, name):
+    """The other eight registered policies (policy.py:437-684) against the reference-run fixtures.
+    Geometry-only policies: exact.  GreedyDP: the walk is exact given the same look-up table and
+    numpy seed; through the device's own table (<= 2e-6 from numpy's) the trajectory matches on
+    most rays.  MaxEntropy / ParallelMaxEntropy: the chosen cells hold the maximum within the
+    table's tolerance, and equal the reference's wherever that maximum is not a near-tie."""
+    c = lc_case(name)
+    ci = LC_CASES.index(name)
+    dev_obj = _device(c)
+    dev_obj.CAMERA_PARAMS = dict(c["cam"])
+    cm = c["confidence_map"]
+    for pname in ("FixedParallel15", "FixedParallel30", "FixedParallel45"):
+        got = lc.get_lc_policy_class(pname)(dev_obj).get_design_points(cm)
+        assert np.array_equal(got, c["policy/" + pname])
+    np.random.seed(77 + ci)
+    assert np.array_equal(lc.RandomParallel(dev_obj).get_design_points(cm),
+                          c["policy/RandomParallel"])
+    ul = O.entropy_lookup(cm)
+    e = ul[1:].reshape(cm.shape[:2])
+    # MaxEntropy
+    got = lc.MaxEntropy(dev_obj).get_design_points(cm)
+    want = c["policy/MaxEntropy"]
+    assert got.shape == want.shape and got.dtype == want.dtype
+    zi = np.array([np.nonzero(cm[i, :, 1] == got[i, 1])[0][0] for i in range(len(got))])
+    assert np.all(e[np.arange(len(zi)), zi] >= e.max(axis=1) - 2 * ENTROPY_ATOL)
+    assert np.all(got[:, 0] == want[:, 0]) and (got[:, 1] == want[:, 1]).mean() >= 0.97
+    # ParallelMaxEntropy
+    got = lc.ParallelMaxEntropy(dev_obj).get_design_points(cm)
+    want = c["policy/ParallelMaxEntropy"]
+    assert got.shape == want.shape and np.array_equal(got[:, 0], want[:, 0])
+    th = np.rad2deg(np.arctan2(cm[:, :, 1], cm[:, :, 0]))
+    fov = c["cam"]["fov"]
+    ez = (e * ((th > 90 - 0.5 * fov) & (th < 90 + 0.5 * fov))).sum(axis=0, dtype=np.float64)
+    if got[0, 1] != want[0, 1]:  # only a near-tie of the summed entropies may move the curtain
+        zi = int(np.nonzero(cm[0, :, 1] == got[0, 1])[0][0])
+        assert ez[zi] >= ez.max() * (1 - 1e-5)
+    # GreedyDP, both tie rules
+    for pname, ties in (("GreedyDPTiesMinVel", "minvel"), ("GreedyDPTiesRandom", "random")):
+        pol = lc.get_lc_policy_class(pname)(dev_obj, int(c["pts_per_cam_ray"]))
+        pol.set_map_geometry(cm[:, :, :2])
+        np.random.seed(77 + ci)
+        assert np.array_equal(pol._walk(ul), c["policy/" + pname])  # same table: exact
+        np.random.seed(77 + ci)
+        got = pol.get_design_points(cm)                              # the device's table
+        want = c["policy/" + pname]
+        if ties == "minvel" and got.shape == want.shape:
+            assert np.all(got == want, axis=1).mean() >= 0.9
+        assert got.shape[1] == 2 and got.dtype == np.float64

@@ -89,3 +89,27 @@ def test_registry_names():
     assert lc.get_lc_policy_class("DPOptimizedPolicy") is lc.DPOptimizedPolicy
     with pytest.raises(AssertionError):
         lc.get_lc_policy_class("NoSuchPolicy")
+
+
+@pytest.mark.parametrize("name", LC_CASES)
+def test_oracle_matches_the_other_reference_policies(name):
+    """policy.py:437-684: fixed / random fronto-parallel curtains, MaxEntropy, ParallelMaxEntropy,
+    GreedyDP with both tie rules -- bit for bit (the random ones from the same numpy seed)."""
+    c = lc_case(name)
+    ci = LC_CASES.index(name)
+    cm, fov = c["confidence_map"], c["cam"]["fov"]
+    for z, pname in ((15, "FixedParallel15"), (30, "FixedParallel30"), (45, "FixedParallel45")):
+        assert np.array_equal(O.fixed_parallel(fov, z), c["policy/" + pname])
+    np.random.seed(77 + ci)
+    assert np.array_equal(O.fixed_parallel(fov, np.random.uniform(5, 60)),
+                          c["policy/RandomParallel"])
+    assert np.array_equal(O.max_entropy(cm), c["policy/MaxEntropy"])
+    assert np.array_equal(O.parallel_max_entropy(cm, fov), c["policy/ParallelMaxEntropy"])
+    nodes, th = O.build_graph(cm[:, :, :2], c["cam"], c["cTl"], int(c["pts_per_cam_ray"]))
+    ul = O.entropy_lookup(cm)
+    np.random.seed(77 + ci)  # the first point's tie is always broken at random (policy.py:470-474)
+    got = O.greedy_dp(ul, nodes, th, float(c["max_dtheta"]), "minvel")
+    assert np.array_equal(got, c["policy/GreedyDPTiesMinVel"])
+    np.random.seed(77 + ci)
+    got = O.greedy_dp(ul, nodes, th, float(c["max_dtheta"]), "random")
+    assert np.array_equal(got, c["policy/GreedyDPTiesRandom"])
