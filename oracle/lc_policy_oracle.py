@@ -17,6 +17,7 @@ Follows:
   interpolate_k         policy.py:114-152
   build_graph           policy.py:160-281
   dp_design             policy.py:283-434
+  greedy_dp, max_entropy, parallel_max_entropy, fixed_parallel      policy.py:437-684
 """
 import math
 
