@@ -1423,6 +1423,8 @@ static bool tc_two_sets_fit(int CIN, int COUT, int kvol, int rows, int tr, bool 
     return (long long)per_cu * 256 >= (rows + tr - 1) / tr;
 }
 
+#include "conv_q4.h"
+
 template <int CIN, int COUT>
 static int cv_launch_tc(const float *feat, const float *wimg, const int *nbr, int k_cap,
                         const int *k_dev, int kvol, int cin, int cout, const float *scale,
@@ -1434,6 +1436,10 @@ static int cv_launch_tc(const float *feat, const float *wimg, const int *nbr, in
     const LcfOpts op = lcf_opts();
     const int rows = op.rows_hint > 0 && op.rows_hint < k_cap ? op.rows_hint : k_cap;
     const int tr = tc_tile_rows(rows);
+    // quad-row form (conv_q4.h): LCF_OPT_CONV_IMPL = 5
+    if (q4_shape_ok<CIN, COUT>() && cin == CIN && cout == COUT && op.conv_impl == 5)
+        return cv_launch_q4<CIN, COUT>(feat, wimg, nbr, k_cap, k_dev, kvol, scale, shift, relu,
+                                       out, st, tr, dn);
     const bool two = op.conv_sets == 2 ||
                      (op.conv_sets == 0 && tc_two_sets_fit(CIN, COUT, kvol, rows, tr));
     if (two && tc_lds_bytes(CIN, COUT, 32, kvol, false, 2) <= 160 * 1024)
@@ -2169,7 +2175,7 @@ extern "C" int lcf_indice_conv_fwd_planned(const float *feat, const void *wimg, 
     if (!cv_bf16_ok(cin) || !cv_bf16_ok(cout)) return LCF_ERR_UNSUPPORTED;
     call.eff.plan = plan;
     call.eff.plan_tr = tile_rows;
-    call.eff.conv_impl = 2; // tile-compacted
+    if (call.eff.conv_impl != 5) call.eff.conv_impl = 2; // tile-compacted (5: its quad-row form)
     const int *nbr = plan;  // never read: the kernels take the plan's entries
     if (math == 0) {
         if (k_out < 0 || kvol <= 0 || !wimg || (k_out > 0 && (!feat || !out)) ||

@@ -1,0 +1,381 @@
+// conv_q4.h -- indice_conv, quad-row form (cv_q4_kernel; included by conv.hip).
+//
+// The tile-compacted kernel pads every (tile, offset) to 16-row groups because v_mfma_f32_16x16x4
+// has 16 rows: at 14 rows per offset and 32-row tile that is 70-75 % efficiency, and it stages the
+// gathered rows through LDS with a barrier per offset.  v_mfma_f32_4x4x1_16b_f32 is sixteen
+// independent 4x4 rank-1 updates at the same flop rate (512 flop in 2 passes); with the A-matrix
+// broadcast (cbsz = 4, abid = b) all sixteen blocks take block b's A operand, which makes ONE
+// instruction a 4-row x 64-column rank-1 update:
+//     D[vgpr i][lane l] += A[lane 4b + i] * B[lane l]      (A = 4 rows at channel k, B = W[k][l])
+// So groups are 4 rows (8 at 32 output columns: two row quads x 8 column blocks, cbsz = 3), a
+// group's rows are ONE load per lane straight from global memory into the A registers (lane
+// (i, b) holds CPL consecutive channels of row i: no LDS staging, no barrier, no redundancy), and
+// abid walks the channels.
+// A workgroup is one tile of <= 32 rows; its waves are NSETS x KS: set j takes every NSETS-th
+// active offset, and the KS waves of a set split the input channels (32 each), so a wave holds
+// 32 registers of W[o] (read from the same fragment-order image as the other kernels) and can
+// keep the NEXT step's 32 in flight beside them.  Every wave has an output tile of its own in LDS
+// (rows added in ascending offset order); the tiles are summed wave 0 .. NW-1 in the epilogue:
+// deterministic.  There is no barrier between set-up and epilogue.
+// tools/ubench/mfma4x4.hip: semantics of the broadcast and the rate (146 cycles per 16
+// instructions with four chains, 137 with two waves per SIMD; 128 is the 16x16x4 rate).
+#pragma once
+
+template <int CIN, int COUT, int KS_>
+struct Q4Cfg {
+    static constexpr int KS = KS_;                 // waves that split the input channels
+    static constexpr int CW = CIN / KS;            // channels (= W registers) of a wave: 32
+    static constexpr int NB = COUT / 4;            // blocks that share an A operand: 16 or 8
+    static constexpr int CBSZ = NB == 16 ? 4 : 3;
+    static constexpr int R = 4 * (16 / NB);        // rows per group: 4 or 8
+    static constexpr int CPL = CW / NB;            // channels of its row a lane holds: 2 or 4
+    static constexpr int OSTR = COUT;              // output-tile row stride (lane = column)
+    static constexpr int OTE = 33 * OSTR;          // floats of one output tile (32 rows + dump)
+    static constexpr int KL = CIN / 4;             // weight image: [tg][sg][q][r16][4],
+    static constexpr int SG = KL / 4;              //   channel = q * KL + sg * 4 + v
+};
+
+static size_t q4_lds_bytes(int COUT, int kvol, int nw)
+{
+    return (size_t)tc_plan_stride(kvol) * 4 + (size_t)nw * 33 * COUT * 4;
+}
+
+// sb-th block's channels of a group (or of two groups with the same W registers)
+template <int CIN, int COUT, int KS, int SB>
+struct Q4Mac {
+    using C = Q4Cfg<CIN, COUT, KS>;
+    static __device__ __forceinline__ void two(const float (&a0)[C::CPL], const float (&a1)[C::CPL],
+                                               const float (&w)[C::CW], f32x4 &c0, f32x4 &c1)
+    {
+#pragma unroll
+        for (int j = 0; j < C::CPL; ++j) {
+            c0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a0[j], w[SB * C::CPL + j], c0, C::CBSZ, SB, 0);
+            c1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a1[j], w[SB * C::CPL + j], c1, C::CBSZ, SB, 0);
+        }
+        if constexpr (SB + 1 < C::NB) Q4Mac<CIN, COUT, KS, SB + 1>::two(a0, a1, w, c0, c1);
+    }
+    // one group: two chains over alternate blocks (a dependent chain issues at 14.6 cycles per
+    // instruction, two at 9.5)
+    static __device__ __forceinline__ void one(const float (&a0)[C::CPL], const float (&w)[C::CW],
+                                               f32x4 &c0, f32x4 &c1)
+    {
+#pragma unroll
+        for (int j = 0; j < C::CPL; ++j) {
+            if constexpr ((SB & 1) == 0)
+                c0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a0[j], w[SB * C::CPL + j], c0, C::CBSZ, SB, 0);
+            else
+                c1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a0[j], w[SB * C::CPL + j], c1, C::CBSZ, SB, 0);
+        }
+        if constexpr (SB + 1 < C::NB) Q4Mac<CIN, COUT, KS, SB + 1>::one(a0, w, c0, c1);
+    }
+};
+
+// TEMP: per-workgroup timestamps (LCF_Q4_ABLATE bit 6)
+__device__ unsigned long long q4_dbg[8 * 4096];
+__device__ unsigned long long q4_dbg2[2 * 64]; // per-step stamps of wave 0 of workgroups 600 / 1250
+extern "C" int lcf_q4_debug_read2(void *dst)
+{
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(q4_dbg2), sizeof(q4_dbg2)) == hipSuccess ? 0 : -1;
+}
+extern "C" int lcf_q4_debug_read(void *dst)
+{
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(q4_dbg), sizeof(q4_dbg)) == hipSuccess ? 0 : -1;
+}
+
+template <int CIN, int COUT, int NSETS, int KS_>
+__global__ void __launch_bounds__(NSETS * KS_ * 64)
+cv_q4_kernel(const float *__restrict__ feat, const float *__restrict__ wimg,
+             const int *__restrict__ nbr, int k_cap, const int *__restrict__ k_dev, int kvol,
+             const float *__restrict__ scale, const float *__restrict__ shift, int relu,
+             float *__restrict__ out, int tr, TcDense dn, const int *__restrict__ plan,
+             int plan_stride, int ablate)
+{
+    using C = Q4Cfg<CIN, COUT, KS_>;
+    constexpr int NB = C::NB, R = C::R, CPL = C::CPL, OSTR = C::OSTR, OTE = C::OTE;
+    constexpr int KS = C::KS, CW = C::CW;
+    constexpr int NW = NSETS * KS;
+    constexpr int TT = NW * 64;
+    constexpr int DUMP = 32;
+
+    const int k_out = lcf_count(k_cap, k_dev);
+    const int row0 = blockIdx.x * tr;
+    if (row0 >= k_out) return;
+    const bool dbg = (ablate & 64) && blockIdx.x < 4096;
+    unsigned long long *dq = q4_dbg + 8 * (blockIdx.x & 4095);
+    if (dbg && threadIdx.x == 0) { dq[0] = wall_clock64(); dq[4] = clock64(); }
+
+    extern __shared__ __align__(16) unsigned char smem[];
+    unsigned *ent = reinterpret_cast<unsigned *>(smem);          // the tile's plan record
+    int *cnt = reinterpret_cast<int *>(ent + 32 * kvol);
+    int *gbase = cnt + 64;
+    int *soff = gbase + 64;
+    int *nsteps_p = soff + 64;
+    const int rec = (32 * kvol + 193 + 3) & ~3;                  // = tc_plan_stride(kvol)
+    float *ot0 = reinterpret_cast<float *>(smem) + rec;          // [NW][33][OSTR]
+
+    const int tidw = threadIdx.x;
+    const int lane = tidw & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tidw >> 6);
+    const int set = wave / KS;      // steps set, set + NSETS, ...
+    const int kh = wave % KS;       // input channels [kh * CW, (kh + 1) * CW)
+    float *ot = ot0 + wave * OTE;
+
+    if (plan) {
+        const int4 *src = reinterpret_cast<const int4 *>(plan + (size_t)blockIdx.x * plan_stride);
+        int4 *dst = reinterpret_cast<int4 *>(ent);
+        for (int e = tidw; e < plan_stride / 4; e += TT) dst[e] = src[e];
+        __syncthreads();
+    } else {
+        tc_build_steps<NW, TT>(nbr, row0, tr, kvol, k_out, reinterpret_cast<int *>(ot0), ent, cnt,
+                               gbase, soff, nsteps_p, DUMP);
+    }
+    for (int e = tidw; e < NW * OTE; e += TT) ot0[e] = 0.f; // (the neighbour tile is dead now)
+    const int n_steps = __builtin_amdgcn_readfirstlane(*nsteps_p);
+    __syncthreads();
+    if (dbg && threadIdx.x == 0) { dq[1] = wall_clock64(); dq[5] = clock64(); }
+
+    // lane -> (row of the group, block = channel slot, output column)
+    const int h = COUT == 64 ? 0 : (lane >> 5);     // row quad of the group (8-row groups)
+    const int rg = h * 4 + (lane & 3);
+    const int sb = (lane >> 2) & (NB - 1);
+    const int col = lane & (COUT - 1);
+    const float *fbase = feat + kh * CW + sb * CPL;
+
+    struct AReg { float v[CPL]; };
+    auto gather = [&](int ibase, int g) -> AReg {
+        AReg a;
+        const unsigned e = ent[ibase + R * g + rg];
+        const float *src = fbase + (size_t)((ablate & 2) ? ((e >> 7) & 63u) : (e >> 7)) * CIN;
+        if constexpr (CPL == 8) {
+            const float4 x = reinterpret_cast<const float4 *>(src)[0];
+            const float4 y = reinterpret_cast<const float4 *>(src)[1];
+            a.v[0] = x.x; a.v[1] = x.y; a.v[2] = x.z; a.v[3] = x.w;
+            a.v[4] = y.x; a.v[5] = y.y; a.v[6] = y.z; a.v[7] = y.w;
+        } else if constexpr (CPL == 4) {
+            const float4 x = *reinterpret_cast<const float4 *>(src);
+            a.v[0] = x.x; a.v[1] = x.y; a.v[2] = x.z; a.v[3] = x.w;
+        } else {
+            const float2 x = *reinterpret_cast<const float2 *>(src);
+            a.v[0] = x.x; a.v[1] = x.y;
+        }
+        return a;
+    };
+    // W[o][k][col] for this wave's channels k = kh * CW + c, from the fragment-order image
+    // [o][tg][sg][q][r16][4] (channel = q * KL + sg * 4 + v): piece m = channels [4m, 4m + 4) of
+    // the wave = q (4 / KS) * kh + 4m / KL, sg = (4m % KL) / 4
+    const int wlane = ((col >> 4) * C::SG * 4 + kh * (4 / KS)) * 16 + (col & 15);
+    auto bload = [&](int o, float (&w)[CW]) {
+        const float4 *wo =
+            reinterpret_cast<const float4 *>(wimg + (size_t)((ablate & 1) ? 0 : o) * CIN * COUT) +
+            wlane;
+#pragma unroll
+        for (int m = 0; m < CW / 4; ++m) {
+            const int q = (4 * m) / C::KL, sg = ((4 * m) % C::KL) / 4;
+            const float4 x = wo[(sg * 4 + q) * 16];
+            w[4 * m + 0] = x.x;
+            w[4 * m + 1] = x.y;
+            w[4 * m + 2] = x.z;
+            w[4 * m + 3] = x.w;
+        }
+    };
+    // tile[output rows of the group][col] += result (vgpr i = row 4h + i of the group)
+    auto add_out = [&](const f32x4 &acc, int ibase, int g) {
+        if (ablate & 32) return;
+        const uint4 e4 = *reinterpret_cast<const uint4 *>(ent + ibase + R * g + 4 * h);
+        float *p0 = ot + (e4.x & 127u) * OSTR + col;
+        float *p1 = ot + (e4.y & 127u) * OSTR + col;
+        float *p2 = ot + (e4.z & 127u) * OSTR + col;
+        float *p3 = ot + (e4.w & 127u) * OSTR + col;
+        const float c0 = *p0, c1 = *p1, c2 = *p2, c3 = *p3;
+        *p0 = c0 + acc[0];
+        *p1 = c1 + acc[1];
+        *p2 = c2 + acc[2];
+        *p3 = c3 + acc[3];
+    };
+
+    if (set < n_steps && !(ablate & 8)) {
+        // Everything that steers is wave-uniform (SGPRs).  Step metadata of this step and the next.
+        int s = set;
+        int o = __builtin_amdgcn_readfirstlane(soff[s]);
+        int ng = (__builtin_amdgcn_readfirstlane(cnt[o]) + R - 1) / R;
+        int ib = __builtin_amdgcn_readfirstlane(gbase[o]) * 16;
+        bool have_next;
+        int no = o, nng = 0, nib = 0;
+        auto next_meta = [&]() {
+            have_next = s + NSETS < n_steps;
+            no = __builtin_amdgcn_readfirstlane(soff[have_next ? s + NSETS : s]);
+            nng = (__builtin_amdgcn_readfirstlane(cnt[no]) + R - 1) / R;
+            nib = __builtin_amdgcn_readfirstlane(gbase[no]) * 16;
+        };
+        next_meta();
+        // Groups go in pairs (one W register feeds two independent accumulator chains).  The
+        // rows of the NEXT pair -- of this step or the first of the next -- are loaded behind
+        // this pair's MFMAs; both loads always go (a missing group repeats its neighbour:
+        // cached), so that the number of loads in flight at every wait is known when the kernel
+        // is compiled (behind a branch the waits would have to assume they were not issued and
+        // drain the queue).  W[o] is reloaded at the step boundary: that round trip is covered by
+        // the SIMD's other waves, not by this one.
+        float w[CW];
+        bload(o, w);
+        AReg n0 = gather(ib, 0), n1 = gather(ib, ng > 1 ? 1 : 0);
+        int g = 0;
+        for (;;) {
+            const AReg a0 = n0, a1 = n1; // waits for this pair's rows
+            // the pair after this one
+            const bool newstep = g + 2 >= ng;
+            const bool more = !newstep || have_next;
+            const int pib = newstep ? nib : ib;
+            const int png = newstep ? nng : ng;
+            const int pg = newstep ? 0 : g + 2;
+            n0 = gather(pib, pg);
+            n1 = gather(pib, pg + 1 < png ? pg + 1 : pg);
+            f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
+            if (ablate & 4) {
+                c0[0] = a0.v[0] + w[0];
+                c1[0] = a1.v[0] + w[1];
+                add_out(c0, ib, g);
+            } else if (g + 1 < ng) {
+                Q4Mac<CIN, COUT, KS, 0>::two(a0.v, a1.v, w, c0, c1);
+                add_out(c0, ib, g);
+                add_out(c1, ib, g + 1);
+            } else {
+                Q4Mac<CIN, COUT, KS, 0>::one(a0.v, w, c0, c1);
+                c0[0] += c1[0];
+                c0[1] += c1[1];
+                c0[2] += c1[2];
+                c0[3] += c1[3];
+                add_out(c0, ib, g);
+            }
+            if (!more) break;
+            g = pg;
+            if (newstep) {
+                bload(no, w);
+                s += NSETS;
+                o = no;
+                ng = nng;
+                ib = nib;
+                next_meta();
+            }
+        }
+    }
+    if (dbg && threadIdx.x == 0) { dq[2] = wall_clock64(); dq[6] = clock64(); }
+    __syncthreads();
+    if (dbg && threadIdx.x == 0) { dq[7] = clock64(); }
+
+    // ---- epilogue: sum of the waves' tiles (wave 0 first), (x*scale + shift), relu, store
+    constexpr int C4 = COUT / 4;
+    for (int e = tidw; e < tr * C4; e += TT) {
+        const int r = e / C4, c4 = e % C4;
+        const int row = row0 + r;
+        if (row < k_out) {
+            float4 v = *reinterpret_cast<const float4 *>(ot0 + r * OSTR + c4 * 4);
+#pragma unroll
+            for (int x = 1; x < NW; ++x) {
+                const float4 v1 =
+                    *reinterpret_cast<const float4 *>(ot0 + x * OTE + r * OSTR + c4 * 4);
+                v.x += v1.x; v.y += v1.y; v.z += v1.z; v.w += v1.w;
+            }
+            if (scale) {
+                const float4 s = *reinterpret_cast<const float4 *>(scale + c4 * 4);
+                v.x *= s.x; v.y *= s.y; v.z *= s.z; v.w *= s.w;
+            }
+            if (shift) {
+                const float4 s = *reinterpret_cast<const float4 *>(shift + c4 * 4);
+                v.x += s.x; v.y += s.y; v.z += s.z; v.w += s.w;
+            }
+            if (relu) {
+                v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f);
+                v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+            }
+            if (dn.coors) {
+                const int4 q = reinterpret_cast<const int4 *>(dn.coors)[row];
+                if (q.x >= 0 && q.x < dn.batch && q.y >= 0 && q.y < dn.D && q.z >= 0 &&
+                    q.z < dn.H && q.w >= 0 && q.w < dn.W) {
+                    const size_t svol = (size_t)dn.D * dn.H * dn.W;
+                    float *d = out + ((size_t)q.x * COUT + c4 * 4) * svol +
+                               ((size_t)q.y * dn.H + q.z) * dn.W + q.w;
+                    d[0] = v.x;
+                    d[svol] = v.y;
+                    d[2 * svol] = v.z;
+                    d[3 * svol] = v.w;
+                }
+            } else {
+                *reinterpret_cast<float4 *>(out + (size_t)row * COUT + c4 * 4) = v;
+            }
+        }
+    }
+    if (dbg && threadIdx.x == 0) dq[3] = wall_clock64();
+}
+
+template <int CIN, int COUT>
+static constexpr bool q4_shape_ok()
+{
+    return (CIN == 32 || CIN == 64) && (COUT == 32 || COUT == 64);
+}
+
+template <int CIN, int COUT, int NSETS, int KS>
+static int cv_launch_q4_n(const float *feat, const float *wimg, const int *nbr, int k_cap,
+                          const int *k_dev, int kvol, const float *scale, const float *shift,
+                          int relu, float *out, hipStream_t st, int tr, TcDense dn)
+{
+    constexpr int NW = NSETS * KS;
+    const size_t lds = q4_lds_bytes(COUT, kvol, NW);
+    if (tr < 1 || tr > 32) return LCF_ERR_ARG;
+    static size_t lds_set = 0; // per instantiation: largest dynamic LDS size opted into so far
+    static std::mutex lds_mu;
+    {
+        std::lock_guard<std::mutex> lock(lds_mu);
+        if (lds > 64 * 1024 && lds > lds_set) {
+            if (hipFuncSetAttribute((const void *)cv_q4_kernel<CIN, COUT, NSETS, KS>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lds) != hipSuccess)
+                return LCF_ERR_LAUNCH;
+            lds_set = lds;
+        }
+    }
+    const LcfOpts op = lcf_opts();
+    const int *plan = op.plan;
+    const int pstride = plan ? tc_plan_stride(kvol) : 0;
+    if (plan && op.plan_tr != tr) return LCF_ERR_ARG;
+    const int nb = (k_cap + tr - 1) / tr;
+    const char *ab = getenv("LCF_Q4_ABLATE"); // TEMP: timing ablations
+    const int ablate = ab ? atoi(ab) : 0;
+    cv_q4_kernel<CIN, COUT, NSETS, KS><<<nb, NW * 64, lds, st>>>(feat, wimg, nbr, k_cap, k_dev, kvol,
+                                                             scale, shift, relu, out, tr, dn,
+                                                             plan, pstride, ablate);
+    LCF_CHECK_LAUNCH();
+    return LCF_OK;
+}
+
+template <int CIN, int COUT>
+static int cv_launch_q4(const float *feat, const float *wimg, const int *nbr, int k_cap,
+                        const int *k_dev, int kvol, const float *scale, const float *shift,
+                        int relu, float *out, hipStream_t st, int tr, TcDense dn)
+{
+    if constexpr (q4_shape_ok<CIN, COUT>()) {
+        const int sets = lcf_opts().conv_sets;
+        const char *ks = getenv("LCF_Q4_KS"); // TEMP
+        if (CIN == 64 && ks && atoi(ks) == 2) {
+            if (sets == 1)
+                return cv_launch_q4_n<CIN, COUT, 1, CIN / 32>(feat, wimg, nbr, k_cap, k_dev, kvol, scale, shift,
+                                                    relu, out, st, tr, dn);
+            if (sets == 2)
+                return cv_launch_q4_n<CIN, COUT, 2, CIN / 32>(feat, wimg, nbr, k_cap, k_dev, kvol, scale, shift,
+                                                    relu, out, st, tr, dn);
+            return cv_launch_q4_n<CIN, COUT, 4, CIN / 32>(feat, wimg, nbr, k_cap, k_dev, kvol, scale, shift,
+                                                relu, out, st, tr, dn);
+        }
+        if (sets == 1)
+            return cv_launch_q4_n<CIN, COUT, 1, 1>(feat, wimg, nbr, k_cap, k_dev, kvol, scale, shift,
+                                                relu, out, st, tr, dn);
+        if (sets == 2)
+            return cv_launch_q4_n<CIN, COUT, 2, 1>(feat, wimg, nbr, k_cap, k_dev, kvol, scale, shift,
+                                                relu, out, st, tr, dn);
+        if (ks && atoi(ks) == 3)
+            return cv_launch_q4_n<CIN, COUT, 3, 1>(feat, wimg, nbr, k_cap, k_dev, kvol, scale, shift,
+                                                relu, out, st, tr, dn);
+        return cv_launch_q4_n<CIN, COUT, 4, 1>(feat, wimg, nbr, k_cap, k_dev, kvol, scale, shift,
+                                            relu, out, st, tr, dn);
+    }
+    return LCF_ERR_UNSUPPORTED;
+}

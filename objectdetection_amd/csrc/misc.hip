@@ -60,7 +60,7 @@ static int opt_store(int option, int value, int *split, int *impl, int *tile, in
         *split = value;
         return LCF_OK;
     case LCF_OPT_CONV_IMPL:
-        if (value < 0 || value > 4) return LCF_ERR_ARG;
+        if (value < 0 || value > 5) return LCF_ERR_ARG;
         *impl = value;
         return LCF_OK;
     case LCF_OPT_CONV_TILE:
@@ -68,7 +68,7 @@ static int opt_store(int option, int value, int *split, int *impl, int *tile, in
         *tile = value;
         return LCF_OK;
     case LCF_OPT_CONV_SETS:
-        if (value < 0 || value > 2) return LCF_ERR_ARG;
+        if (value < 0 || (value > 2 && value != 4)) return LCF_ERR_ARG;
         *sets = value;
         return LCF_OK;
     default: return LCF_ERR_ARG;
