@@ -35,10 +35,11 @@ HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md "HBM3E peak BW" (spec)
 
 
 def dominant_kernel_roofline(model, clouds, math="f32", reps=20):
-    """Times every launch of the dominant kernel -- the 64->64 channel indice_conv (fused
-    gather-GEMM-scatter + BN + ReLU), cv_tc_kernel<64,64,32>: fp32 MFMA over tile plans as
-    FrameEngine launches it (math "f32"), or with bf16 MFMA operands over neighbour tables as the
-    training step launches it (math "bf16") -- with HIP events on the stream it is launched on,
+    """Times every launch of the dominant kernel -- the 3x3x3, 64->64 channel indice_conv (fused
+    gather-GEMM-scatter + BN + ReLU): cv_q4_kernel<64,64,4>, fp32 MFMA over tile plans as
+    FrameEngine launches it (math "f32"; 7 launches per frame), or cv_tc_kernel<64,64,32> with
+    bf16 MFMA operands over neighbour tables as the training step launches it (math "bf16") --
+    with HIP events on the stream it is launched on,
     after the timed region.  achieved = algorithmic flops per launch (2 * pairs * Cin * Cout,
     SURVEY.md section 8d) / average launch duration; the same launches priced in algorithmic
     bytes (K_in*Cin*4 + K_out*Cout*4 + K_out*kvol*4 + kvol*Cin*Cout*e) against HBM."""
@@ -55,7 +56,8 @@ def dominant_kernel_roofline(model, clouds, math="f32", reps=20):
         conv, bn = mods[i], mods[i + 1]
         rb = conv.get_rulebook(x)
         scale, shift = _bn_affine(bn)
-        if conv.in_channels == 64 and conv.out_channels == 64:
+        if conv.in_channels == 64 and conv.out_channels == 64 and (math != "f32" or
+                                                                   rb.kvol == 27):
             pairs = int((rb.out_nbr >= 0).sum().item())
             nbytes = 4 * (rb.k_in * 64 + rb.k_out * 64 + rb.k_out * rb.kvol) + \
                 rb.kvol * 64 * 64 * (4 if math == "f32" else 2)
@@ -97,7 +99,8 @@ def dominant_kernel_roofline(model, clouds, math="f32", reps=20):
                 traffic = json.load(fh)["hbm_bytes_per_launch"]
         except (OSError, KeyError, ValueError):
             pass
-    common = {"kernel": "cv_tc_kernel<64,64,32>" + ("" if math == "f32" else " (bf16 operands)"),
+    common = {"kernel": "cv_q4_kernel<64,64,4>" if math == "f32" else
+              "cv_tc_kernel<64,64,32> (bf16 operands)",
               "launches_per_frame" if math == "f32" else "launches_timed": n,
               "avg_launch_us": round(avg_s * 1e6, 2),
               "flops_per_launch": round(total_flops / n, 0),

@@ -1436,8 +1436,9 @@ static int cv_launch_tc(const float *feat, const float *wimg, const int *nbr, in
     const LcfOpts op = lcf_opts();
     const int rows = op.rows_hint > 0 && op.rows_hint < k_cap ? op.rows_hint : k_cap;
     const int tr = tc_tile_rows(rows);
-    // quad-row form (conv_q4.h): LCF_OPT_CONV_IMPL = 5
-    if (q4_shape_ok<CIN, COUT>() && cin == CIN && cout == COUT && op.conv_impl == 5)
+    // quad-row form (conv_q4.h): the default for the 3x3x3 convs of 32 / 64 channels
+    if (q4_shape_ok<CIN, COUT>() && cin == CIN && cout == COUT &&
+        (op.conv_impl == 5 || (op.conv_impl == 0 && kvol >= 9)))
         return cv_launch_q4<CIN, COUT>(feat, wimg, nbr, k_cap, k_dev, kvol, scale, shift, relu,
                                        out, st, tr, dn);
     const bool two = op.conv_sets == 2 ||
@@ -2175,7 +2176,8 @@ extern "C" int lcf_indice_conv_fwd_planned(const float *feat, const void *wimg, 
     if (!cv_bf16_ok(cin) || !cv_bf16_ok(cout)) return LCF_ERR_UNSUPPORTED;
     call.eff.plan = plan;
     call.eff.plan_tr = tile_rows;
-    if (call.eff.conv_impl != 5) call.eff.conv_impl = 2; // tile-compacted (5: its quad-row form)
+    // (tile-compacted kernels only: 0 / 5 let cv_launch_tc pick the quad-row form)
+    if (call.eff.conv_impl != 5 && call.eff.conv_impl != 0) call.eff.conv_impl = 2;
     const int *nbr = plan;  // never read: the kernels take the plan's entries
     if (math == 0) {
         if (k_out < 0 || kvol <= 0 || !wimg || (k_out > 0 && (!feat || !out)) ||

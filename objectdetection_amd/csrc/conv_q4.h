@@ -11,14 +11,21 @@
 // group's rows are ONE load per lane straight from global memory into the A registers (lane
 // (i, b) holds CPL consecutive channels of row i: no LDS staging, no barrier, no redundancy), and
 // abid walks the channels.
-// A workgroup is one tile of <= 32 rows; its waves are NSETS x KS: set j takes every NSETS-th
-// active offset, and the KS waves of a set split the input channels (32 each), so a wave holds
-// 32 registers of W[o] (read from the same fragment-order image as the other kernels) and can
-// keep the NEXT step's 32 in flight beside them.  Every wave has an output tile of its own in LDS
-// (rows added in ascending offset order); the tiles are summed wave 0 .. NW-1 in the epilogue:
-// deterministic.  There is no barrier between set-up and epilogue.
+// A workgroup is one tile of <= 32 rows; its NSETS waves each take every NSETS-th active offset
+// alone: W[o] in Cin registers (read from the same fragment-order image as the other kernels),
+// an output tile of its own in LDS (rows added in ascending offset order; the tiles are summed
+// wave 0 .. NSETS-1 in the epilogue: deterministic), and no barrier between set-up and epilogue.
+// (KS > 1 splits the input channels over KS waves per set, so that the next step's W fits beside
+// this step's; built and measured, not instantiated: twice the output tiles and gathers cost
+// more than the hidden round trip gains.)
 // tools/ubench/mfma4x4.hip: semantics of the broadcast and the rate (146 cycles per 16
 // instructions with four chains, 137 with two waves per SIMD; 128 is the 16x16x4 rate).
+// What it measures (tools/bench_q4.py): level with the tile-compacted kernel
+// on the submanifold layers, ahead of it on the strided ones (few rows per offset: 16-row groups
+// are mostly padding there); inside the frame, beside the rulebook branch, ahead on all of them
+// (0.695 -> 0.636 ms per frame, tools/ab_q4.py): the default for 27-offset convs with 32 / 64
+// channels.  LCF_OPT_CONV_IMPL = 2 keeps the tile-compacted kernel, 5 asks for this one;
+// LCF_OPT_CONV_SETS = 1..4 waves per tile (default 3 at 32 input channels, 4 at 64).
 #pragma once
 
 template <int CIN, int COUT, int KS_>
@@ -44,13 +51,19 @@ static size_t q4_lds_bytes(int COUT, int kvol, int nw)
 template <int CIN, int COUT, int KS, int SB>
 struct Q4Mac {
     using C = Q4Cfg<CIN, COUT, KS>;
+    // Every group's result is (sum over the even blocks' channels) + (sum over the odd blocks'),
+    // each in ascending channel order, whether the group runs alone or beside another: a row's
+    // value does not depend on how its tile was cut (engine and module path agree bit for bit).
     static __device__ __forceinline__ void two(const float (&a0)[C::CPL], const float (&a1)[C::CPL],
-                                               const float (&w)[C::CW], f32x4 &c0, f32x4 &c1)
+                                               const float (&w)[C::CW], f32x4 (&c0)[2],
+                                               f32x4 (&c1)[2])
     {
 #pragma unroll
         for (int j = 0; j < C::CPL; ++j) {
-            c0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a0[j], w[SB * C::CPL + j], c0, C::CBSZ, SB, 0);
-            c1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a1[j], w[SB * C::CPL + j], c1, C::CBSZ, SB, 0);
+            c0[SB & 1] = __builtin_amdgcn_mfma_f32_4x4x1f32(a0[j], w[SB * C::CPL + j], c0[SB & 1],
+                                                            C::CBSZ, SB, 0);
+            c1[SB & 1] = __builtin_amdgcn_mfma_f32_4x4x1f32(a1[j], w[SB * C::CPL + j], c1[SB & 1],
+                                                            C::CBSZ, SB, 0);
         }
         if constexpr (SB + 1 < C::NB) Q4Mac<CIN, COUT, KS, SB + 1>::two(a0, a1, w, c0, c1);
     }
@@ -70,25 +83,13 @@ struct Q4Mac {
     }
 };
 
-// TEMP: per-workgroup timestamps (LCF_Q4_ABLATE bit 6)
-__device__ unsigned long long q4_dbg[8 * 4096];
-__device__ unsigned long long q4_dbg2[2 * 64]; // per-step stamps of wave 0 of workgroups 600 / 1250
-extern "C" int lcf_q4_debug_read2(void *dst)
-{
-    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(q4_dbg2), sizeof(q4_dbg2)) == hipSuccess ? 0 : -1;
-}
-extern "C" int lcf_q4_debug_read(void *dst)
-{
-    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(q4_dbg), sizeof(q4_dbg)) == hipSuccess ? 0 : -1;
-}
-
 template <int CIN, int COUT, int NSETS, int KS_>
 __global__ void __launch_bounds__(NSETS * KS_ * 64)
 cv_q4_kernel(const float *__restrict__ feat, const float *__restrict__ wimg,
              const int *__restrict__ nbr, int k_cap, const int *__restrict__ k_dev, int kvol,
              const float *__restrict__ scale, const float *__restrict__ shift, int relu,
              float *__restrict__ out, int tr, TcDense dn, const int *__restrict__ plan,
-             int plan_stride, int ablate)
+             int plan_stride)
 {
     using C = Q4Cfg<CIN, COUT, KS_>;
     constexpr int NB = C::NB, R = C::R, CPL = C::CPL, OSTR = C::OSTR, OTE = C::OTE;
@@ -100,9 +101,6 @@ cv_q4_kernel(const float *__restrict__ feat, const float *__restrict__ wimg,
     const int k_out = lcf_count(k_cap, k_dev);
     const int row0 = blockIdx.x * tr;
     if (row0 >= k_out) return;
-    const bool dbg = (ablate & 64) && blockIdx.x < 4096;
-    unsigned long long *dq = q4_dbg + 8 * (blockIdx.x & 4095);
-    if (dbg && threadIdx.x == 0) { dq[0] = wall_clock64(); dq[4] = clock64(); }
 
     extern __shared__ __align__(16) unsigned char smem[];
     unsigned *ent = reinterpret_cast<unsigned *>(smem);          // the tile's plan record
@@ -132,7 +130,6 @@ cv_q4_kernel(const float *__restrict__ feat, const float *__restrict__ wimg,
     for (int e = tidw; e < NW * OTE; e += TT) ot0[e] = 0.f; // (the neighbour tile is dead now)
     const int n_steps = __builtin_amdgcn_readfirstlane(*nsteps_p);
     __syncthreads();
-    if (dbg && threadIdx.x == 0) { dq[1] = wall_clock64(); dq[5] = clock64(); }
 
     // lane -> (row of the group, block = channel slot, output column)
     const int h = COUT == 64 ? 0 : (lane >> 5);     // row quad of the group (8-row groups)
@@ -145,7 +142,7 @@ cv_q4_kernel(const float *__restrict__ feat, const float *__restrict__ wimg,
     auto gather = [&](int ibase, int g) -> AReg {
         AReg a;
         const unsigned e = ent[ibase + R * g + rg];
-        const float *src = fbase + (size_t)((ablate & 2) ? ((e >> 7) & 63u) : (e >> 7)) * CIN;
+        const float *src = fbase + (size_t)(e >> 7) * CIN;
         if constexpr (CPL == 8) {
             const float4 x = reinterpret_cast<const float4 *>(src)[0];
             const float4 y = reinterpret_cast<const float4 *>(src)[1];
@@ -166,7 +163,7 @@ cv_q4_kernel(const float *__restrict__ feat, const float *__restrict__ wimg,
     const int wlane = ((col >> 4) * C::SG * 4 + kh * (4 / KS)) * 16 + (col & 15);
     auto bload = [&](int o, float (&w)[CW]) {
         const float4 *wo =
-            reinterpret_cast<const float4 *>(wimg + (size_t)((ablate & 1) ? 0 : o) * CIN * COUT) +
+            reinterpret_cast<const float4 *>(wimg + (size_t)o * CIN * COUT) +
             wlane;
 #pragma unroll
         for (int m = 0; m < CW / 4; ++m) {
@@ -180,7 +177,6 @@ cv_q4_kernel(const float *__restrict__ feat, const float *__restrict__ wimg,
     };
     // tile[output rows of the group][col] += result (vgpr i = row 4h + i of the group)
     auto add_out = [&](const f32x4 &acc, int ibase, int g) {
-        if (ablate & 32) return;
         const uint4 e4 = *reinterpret_cast<const uint4 *>(ent + ibase + R * g + 4 * h);
         float *p0 = ot + (e4.x & 127u) * OSTR + col;
         float *p1 = ot + (e4.y & 127u) * OSTR + col;
@@ -193,7 +189,7 @@ cv_q4_kernel(const float *__restrict__ feat, const float *__restrict__ wimg,
         *p3 = c3 + acc[3];
     };
 
-    if (set < n_steps && !(ablate & 8)) {
+    if (set < n_steps) {
         // Everything that steers is wave-uniform (SGPRs).  Step metadata of this step and the next.
         int s = set;
         int o = __builtin_amdgcn_readfirstlane(soff[s]);
@@ -230,12 +226,11 @@ cv_q4_kernel(const float *__restrict__ feat, const float *__restrict__ wimg,
             n0 = gather(pib, pg);
             n1 = gather(pib, pg + 1 < png ? pg + 1 : pg);
             f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
-            if (ablate & 4) {
-                c0[0] = a0.v[0] + w[0];
-                c1[0] = a1.v[0] + w[1];
-                add_out(c0, ib, g);
-            } else if (g + 1 < ng) {
-                Q4Mac<CIN, COUT, KS, 0>::two(a0.v, a1.v, w, c0, c1);
+            if (g + 1 < ng) {
+                f32x4 p0[2] = {c0, c0}, p1[2] = {c0, c0};
+                Q4Mac<CIN, COUT, KS, 0>::two(a0.v, a1.v, w, p0, p1);
+                c0 = p0[0] + p0[1];
+                c1 = p1[0] + p1[1];
                 add_out(c0, ib, g);
                 add_out(c1, ib, g + 1);
             } else {
@@ -258,9 +253,7 @@ cv_q4_kernel(const float *__restrict__ feat, const float *__restrict__ wimg,
             }
         }
     }
-    if (dbg && threadIdx.x == 0) { dq[2] = wall_clock64(); dq[6] = clock64(); }
     __syncthreads();
-    if (dbg && threadIdx.x == 0) { dq[7] = clock64(); }
 
     // ---- epilogue: sum of the waves' tiles (wave 0 first), (x*scale + shift), relu, store
     constexpr int C4 = COUT / 4;
@@ -304,7 +297,6 @@ cv_q4_kernel(const float *__restrict__ feat, const float *__restrict__ wimg,
             }
         }
     }
-    if (dbg && threadIdx.x == 0) dq[3] = wall_clock64();
 }
 
 template <int CIN, int COUT>
@@ -338,11 +330,9 @@ static int cv_launch_q4_n(const float *feat, const float *wimg, const int *nbr, 
     const int pstride = plan ? tc_plan_stride(kvol) : 0;
     if (plan && op.plan_tr != tr) return LCF_ERR_ARG;
     const int nb = (k_cap + tr - 1) / tr;
-    const char *ab = getenv("LCF_Q4_ABLATE"); // TEMP: timing ablations
-    const int ablate = ab ? atoi(ab) : 0;
     cv_q4_kernel<CIN, COUT, NSETS, KS><<<nb, NW * 64, lds, st>>>(feat, wimg, nbr, k_cap, k_dev, kvol,
                                                              scale, shift, relu, out, tr, dn,
-                                                             plan, pstride, ablate);
+                                                             plan, pstride);
     LCF_CHECK_LAUNCH();
     return LCF_OK;
 }
@@ -354,28 +344,14 @@ static int cv_launch_q4(const float *feat, const float *wimg, const int *nbr, in
 {
     if constexpr (q4_shape_ok<CIN, COUT>()) {
         const int sets = lcf_opts().conv_sets;
-        const char *ks = getenv("LCF_Q4_KS"); // TEMP
-        if (CIN == 64 && ks && atoi(ks) == 2) {
-            if (sets == 1)
-                return cv_launch_q4_n<CIN, COUT, 1, CIN / 32>(feat, wimg, nbr, k_cap, k_dev, kvol, scale, shift,
-                                                    relu, out, st, tr, dn);
-            if (sets == 2)
-                return cv_launch_q4_n<CIN, COUT, 2, CIN / 32>(feat, wimg, nbr, k_cap, k_dev, kvol, scale, shift,
-                                                    relu, out, st, tr, dn);
-            return cv_launch_q4_n<CIN, COUT, 4, CIN / 32>(feat, wimg, nbr, k_cap, k_dev, kvol, scale, shift,
-                                                relu, out, st, tr, dn);
-        }
-        if (sets == 1)
-            return cv_launch_q4_n<CIN, COUT, 1, 1>(feat, wimg, nbr, k_cap, k_dev, kvol, scale, shift,
-                                                relu, out, st, tr, dn);
-        if (sets == 2)
-            return cv_launch_q4_n<CIN, COUT, 2, 1>(feat, wimg, nbr, k_cap, k_dev, kvol, scale, shift,
-                                                relu, out, st, tr, dn);
-        if (ks && atoi(ks) == 3)
-            return cv_launch_q4_n<CIN, COUT, 3, 1>(feat, wimg, nbr, k_cap, k_dev, kvol, scale, shift,
-                                                relu, out, st, tr, dn);
-        return cv_launch_q4_n<CIN, COUT, 4, 1>(feat, wimg, nbr, k_cap, k_dev, kvol, scale, shift,
-                                            relu, out, st, tr, dn);
+#define Q4_GO(NS)                                                                                  \
+    return cv_launch_q4_n<CIN, COUT, NS, 1>(feat, wimg, nbr, k_cap, k_dev, kvol, scale, shift,     \
+                                            relu, out, st, tr, dn)
+        if (sets == 1) Q4_GO(1);
+        if (sets == 2) Q4_GO(2);
+        if (sets == 3 || (sets == 0 && CIN == 32)) Q4_GO(3);
+        Q4_GO(4); // (5 and 6 waves lose to 4, 8 is level with it: tools/ab_q4.py)
+#undef Q4_GO
     }
     return LCF_ERR_UNSUPPORTED;
 }

@@ -68,7 +68,7 @@ static int opt_store(int option, int value, int *split, int *impl, int *tile, in
         *tile = value;
         return LCF_OK;
     case LCF_OPT_CONV_SETS:
-        if (value < 0 || (value > 2 && value != 4)) return LCF_ERR_ARG;
+        if (value < 0 || value > 4) return LCF_ERR_ARG;
         *sets = value;
         return LCF_OK;
     default: return LCF_ERR_ARG;

@@ -336,6 +336,72 @@ def test_tile_compacted_variants_match_oracle(oracle, cuda, cin, cout, sets, til
     assert torch.equal(out, again)
 
 
+@pytest.mark.parametrize("cin,cout", [(32, 32), (64, 64), (32, 64), (64, 32)])
+@pytest.mark.parametrize("sets,tile,subm", [(0, 0, True), (1, 32, True), (2, 17, True),
+                                            (3, 25, False), (4, 32, False), (4, 16, True)])
+def test_quad_row_form_matches_oracle(oracle, cuda, cin, cout, sets, tile, subm):
+    """cv_q4_kernel (csrc/conv_q4.h: v_mfma_f32_4x4x1 with the A-matrix broadcast, 4- or 8-row
+    groups gathered straight into registers), every number of waves per tile and several tile
+    heights, submanifold and strided, against the oracle; run-to-run deterministic; the same
+    through a tile plan and with the row count on the device, bit for bit."""
+    from objectdetection_amd import _lib
+    from objectdetection_amd._lib import check, i3
+    rng = np.random.default_rng(cin + 7 * cout + sets + tile)
+    coors = _frame_coors(oracle, 4, 7000)
+    extra = coors.copy()
+    extra[:, 2] = np.minimum(extra[:, 2] + 1, 1599)
+    coors = np.ascontiguousarray(np.unique(np.concatenate([coors, extra], 0), axis=0))
+    shape = [41, 1600, 1408]
+    k = coors.shape[0]
+    x = rng.standard_normal((k, cin)).astype(np.float32)
+    w = (rng.standard_normal((3, 3, 3, cin, cout)) / np.sqrt(27 * cin)).astype(np.float32)
+    if subm:
+        pairs, pn = oracle.rulebook_subm(coors, 1, shape, 3)
+        k_out = k
+        rb = ops.build_rulebook(torch.from_numpy(coors).to(cuda), 1, shape, 3, 1, 1, 1, True)
+    else:
+        out_coors, pairs, pn, _ = oracle.rulebook_conv(coors, 1, shape, 3, 2, 1)
+        k_out = out_coors.shape[0]
+        rb = ops.build_rulebook(torch.from_numpy(coors).to(cuda), 1, shape, 3, 2, 1, 1, False)
+        assert rb.k_out == k_out
+    ref = oracle.indice_conv_fwd(x, w, pairs, pn, k_out)
+    xt, wt = torch.from_numpy(x).to(cuda), torch.from_numpy(w).to(cuda)
+    img = ops.weight_image(wt)
+    L = _lib.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    try:
+        assert L.lcf_set_option(_lib.OPT_CONV_IMPL, 5) == 0
+        assert L.lcf_set_option(_lib.OPT_CONV_SETS, sets) == 0
+        assert L.lcf_set_option(_lib.OPT_CONV_TILE, tile) == 0
+        out = ops.conv_forward(xt, img, rb.out_nbr, rb.k_out, 27, cin, cout)
+        again = ops.conv_forward(xt, img, rb.out_nbr, rb.k_out, 27, cin, cout)
+        # a capacity with the count on the device, through a tile plan
+        cap = k_out + 333
+        tr = tile if tile else L.lcf_conv_tile_rows(k_out)
+        nbr = torch.cat([rb.out_nbr, torch.full((333, 27), 5, dtype=torch.int32, device=cuda)])
+        k_dev = torch.tensor([k_out], dtype=torch.int32, device=cuda)
+        plan = torch.zeros(L.lcf_conv_tile_plan_ints(cap, 27, tr), dtype=torch.int32, device=cuda)
+        check(L.lcf_conv_tile_plan(nbr.data_ptr(), cap, k_dev.data_ptr(), 27, tr,
+                                   plan.data_ptr(), st))
+        planned = torch.full((cap, cout), 7.0, device=cuda)
+        ctx = _lib.Context()
+        ctx.set(_lib.OPT_CONV_ROWS_HINT, k_out)
+        check(L.lcf_indice_conv_fwd_planned(
+            xt.data_ptr(), img.data_ptr(), 0, plan.data_ptr(), tr, cap, k_dev.data_ptr(), 27,
+            cin, cout, None, None, 0, planned.data_ptr(), None, 1, i3(0), st, ctx.handle))
+    finally:
+        L.lcf_set_option(_lib.OPT_CONV_IMPL, 0)
+        L.lcf_set_option(_lib.OPT_CONV_SETS, 0)
+        L.lcf_set_option(_lib.OPT_CONV_TILE, 0)
+    assert rel_err(out.cpu().numpy(), ref) < RTOL
+    assert torch.equal(out, again)
+    if tile:  # (tile 0: the heights the two calls pick from their row counts may differ)
+        assert torch.equal(planned[:k_out], out)
+    else:
+        assert rel_err(planned[:k_out].cpu().numpy(), ref) < RTOL
+    assert bool((planned[k_out:] == 7.0).all())
+
+
 @pytest.mark.parametrize("cin,cout,sets", [(64, 64, 1), (64, 64, 2), (16, 16, 1), (32, 128, 2),
                                            (128, 32, 1), (5, 64, 1)])
 def test_conv_with_dense_epilogue_equals_conv_then_dense(oracle, cuda, cin, cout, sets):
@@ -599,8 +665,8 @@ def test_option_values_are_validated(cuda):
     L = _lib.lib()
     assert L.lcf_set_option(_lib.OPT_CONV_TILE, 15) != 0
     assert L.lcf_set_option(_lib.OPT_CONV_TILE, 33) != 0
-    assert L.lcf_set_option(_lib.OPT_CONV_SETS, 3) != 0
-    assert L.lcf_set_option(_lib.OPT_CONV_IMPL, 5) != 0
+    assert L.lcf_set_option(_lib.OPT_CONV_SETS, 5) != 0
+    assert L.lcf_set_option(_lib.OPT_CONV_IMPL, 6) != 0
     assert L.lcf_set_option(99, 0) != 0
     # options that change what a call assumes about its buffers exist per context only
     assert L.lcf_set_option(_lib.OPT_WS_CLEAN, 1) != 0
