@@ -57,15 +57,19 @@ int lcf_version(void);
  * Options (lcf_ctx_set_option; 0 = default):
  * LCF_OPT_CONV_SPLIT: how many waves share one 16-row tile of the slab-form indice_conv forward
  *   by splitting its output columns: 1, 2 or 4; 0 = choose from the row count.
- * LCF_OPT_CONV_IMPL: forward kernel: 0 = per shape (tile-compacted when both channel counts are
- *   >= 32, split-slab for thin layers with <= 32 output channels, slab form for the rest),
+ * LCF_OPT_CONV_IMPL: forward kernel: 0 = per shape (quad-row form for >= 9 offsets with 32 / 64
+ *   channels on both sides, tile-compacted for the other shapes with both channel counts >= 32,
+ *   split-slab for thin layers with <= 32 output channels, slab form for the rest),
  *   1 = slab form wherever it applies, 2 = tile-compacted, 3 = split-slab wherever it applies,
- *   4 = thin-tile (compacted 64-row tiles) wherever it applies (<= 32 output channels).
- * LCF_OPT_CONV_TILE: output rows per workgroup of the tile-compacted forward: 16..32, or 0 = the
- *   largest height <= 32 that deals the tiles evenly over the 256 CUs.
- * LCF_OPT_CONV_SETS: wave sets per workgroup of the tile-compacted forward (a second set takes
- *   every other kernel offset of the tile): 1, 2 or 0 = two when every tile of the launch is
- *   resident at once, judged from the rows the launch expects.
+ *   4 = thin-tile (compacted 64-row tiles) wherever it applies (<= 32 output channels),
+ *   5 = quad-row form wherever it applies (32 / 64 channels on both sides, any offset count).
+ * LCF_OPT_CONV_TILE: output rows per workgroup of the compacted forwards: 16..32, or 0 = the
+ *   largest height <= 32 that deals the tiles evenly over the 256 CUs (tile-compacted form) /
+ *   32 (quad-row form).
+ * LCF_OPT_CONV_SETS: waves (quad-row form: 1..4, 0 = 3 at 32 input channels, 4 at 64) or wave
+ *   sets (tile-compacted form: 1, 2 or 0 = two when every tile of the launch is resident at once,
+ *   judged from the rows the launch expects) that share a tile by taking every n-th kernel
+ *   offset of it.
  * LCF_OPT_CONV_ROWS_HINT: the number of output rows the forward calls made with this context
  *   expect, for callers that pass a capacity as k_out and keep the real count on the device; only
  *   kernel selection reads it (never bounds).  0 = use the k_out passed to the call.

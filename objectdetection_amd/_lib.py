@@ -6,6 +6,8 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liblcf.so")
+if os.environ.get("LCF_LIB"):  # an experimental build of the same library (A/B tools)
+    LIB_PATH = os.path.abspath(os.environ["LCF_LIB"])
 
 c_int = ctypes.c_int
 c_size_t = ctypes.c_size_t

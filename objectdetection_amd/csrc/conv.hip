@@ -1311,8 +1311,7 @@ extern "C" size_t lcf_conv_tile_plan_ints(int k_cap, int kvol, int tile_rows)
 extern "C" int lcf_conv_tile_rows(int rows)
 {
     // the height the tile-compacted forward picks for a launch that expects `rows` rows
-    LcfCall call(nullptr);
-    call.eff.conv_tile = 0;
+    LcfCall call(nullptr); // (the process-wide LCF_OPT_CONV_TILE, if one is set, applies)
     return tc_tile_rows(rows);
 }
 
@@ -1438,9 +1437,13 @@ static int cv_launch_tc(const float *feat, const float *wimg, const int *nbr, in
     const int tr = tc_tile_rows(rows);
     // quad-row form (conv_q4.h): the default for the 3x3x3 convs of 32 / 64 channels
     if (q4_shape_ok<CIN, COUT>() && cin == CIN && cout == COUT &&
-        (op.conv_impl == 5 || (op.conv_impl == 0 && kvol >= 9)))
+        (op.conv_impl == 5 || (op.conv_impl == 0 && kvol >= 9))) {
+        // full tiles: this form has no per-CU balance to strike (32 rows: 0.6336 -> 0.6292 ms per
+        // frame against the balanced heights, tools/ab_tile.py)
+        const int trq = op.plan ? op.plan_tr : (op.conv_tile ? tr : 32);
         return cv_launch_q4<CIN, COUT>(feat, wimg, nbr, k_cap, k_dev, kvol, scale, shift, relu,
-                                       out, st, tr, dn);
+                                       out, st, trq, dn);
+    }
     const bool two = op.conv_sets == 2 ||
                      (op.conv_sets == 0 && tc_two_sets_fit(CIN, COUT, kvol, rows, tr));
     if (two && tc_lds_bytes(CIN, COUT, 32, kvol, false, 2) <= 160 * 1024)

@@ -52,8 +52,10 @@ template <int CIN, int COUT, int KS, int SB>
 struct Q4Mac {
     using C = Q4Cfg<CIN, COUT, KS>;
     // Every group's result is (sum over the even blocks' channels) + (sum over the odd blocks'),
-    // each in ascending channel order, whether the group runs alone or beside another: a row's
-    // value does not depend on how its tile was cut (engine and module path agree bit for bit).
+    // each in ascending channel order, whether the group runs alone or beside another: with one
+    // wave per tile a row's value does not depend on how the tiles were cut; with several it
+    // depends on the tile's list of active offsets (which wave adds which), so the engine and the
+    // module path both cut 32-row tiles and agree bit for bit.
     static __device__ __forceinline__ void two(const float (&a0)[C::CPL], const float (&a1)[C::CPL],
                                                const float (&w)[C::CW], f32x4 (&c0)[2],
                                                f32x4 (&c1)[2])

@@ -787,7 +787,8 @@ def test_planned_forward_is_bit_identical_to_the_table_forward(cuda, math):
         st = torch.cuda.current_stream().cuda_stream
         for cap_extra in (0, 777):  # exact row count, and a capacity with the count on the device
             cap = k + cap_extra
-            tr = L.lcf_conv_tile_rows(k)
+            # (fp32: these shapes run the quad-row kernel, whose table forward cuts 32-row tiles)
+            tr = 32 if math == 0 else L.lcf_conv_tile_rows(k)
             nbr = torch.cat([rb.out_nbr, torch.full((cap_extra, kvol), 5, dtype=torch.int32,
                                                     device=cuda)])
             k_dev = torch.tensor([k], dtype=torch.int32, device=cuda)
