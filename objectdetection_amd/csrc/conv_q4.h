@@ -351,6 +351,15 @@ static int cv_launch_q4(const float *feat, const float *wimg, const int *nbr, in
                                             relu, out, st, tr, dn)
         if (sets == 1) Q4_GO(1);
         if (sets == 2) Q4_GO(2);
+#ifdef Q4_EXP
+        {
+            const LcfOpts op = lcf_opts();
+            const int rows = op.rows_hint > 0 && op.rows_hint < k_cap ? op.rows_hint : k_cap;
+            const int tiles = (rows + tr - 1) / tr;
+            // three waves: 29.6 KB of LDS, five workgroups per CU -- every tile resident at once
+            if (sets == 0 && CIN == 64 && tiles > 1024 && tiles <= 1280) Q4_GO(3);
+        }
+#endif
         if (sets == 3 || (sets == 0 && CIN == 32)) Q4_GO(3);
         Q4_GO(4); // (5 and 6 waves lose to 4, 8 is level with it: tools/ab_q4.py)
 #undef Q4_GO
