@@ -62,7 +62,7 @@ def dominant_kernel_roofline(model, clouds, math="f32", reps=20):
             nbytes = 4 * (rb.k_in * 64 + rb.k_out * 64 + rb.k_out * rb.kvol) + \
                 rb.kvol * 64 * 64 * (4 if math == "f32" else 2)
             if math == "f32":
-                plan, tr = ops.tile_plan(rb.out_nbr, rb.k_out, rb.kvol)
+                plan, tr = ops.tile_plan(rb.out_nbr, rb.k_out, rb.kvol, shape=(64, 64, 0))
                 call = (ops.conv_forward_planned,
                         (x.features, conv._weight_image(), plan, tr, rb.k_out, rb.kvol, 64, 64,
                          scale, shift, True))

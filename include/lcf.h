@@ -345,7 +345,9 @@ int lcf_indice_conv_fwd_dense(const float *feat, const float *wimg, const int *n
  * the result depends on the neighbour table only, so it can be computed ONCE per rulebook and
  * shared by every conv over it (the two or three SubMConv3d of one indice_key,
  * second/pytorch/models/middle.py:146-183) and built off the critical path.
- *   lcf_conv_tile_rows(rows): the tile height the forward picks for a launch expecting `rows`.
+ *   lcf_conv_tile_rows_for(rows, kvol, cin, cout, math): the tile height the default forward of
+ *     that shape and arithmetic picks for a launch expecting `rows` (lcf_conv_tile_rows(rows):
+ *     the tile-compacted kernels' choice, whatever the shape).
  *   lcf_conv_tile_plan: plan [lcf_conv_tile_plan_ints(k, kvol, tile_rows)] int32 (16-byte
  *     aligned) from nbr [k, kvol] (out_nbr for the forward, in_nbr for dgrad); k / k_dev as
  *     everywhere.
@@ -356,6 +358,7 @@ int lcf_indice_conv_fwd_dense(const float *feat, const float *wimg, const int *n
  *     {32, 64, 128}; k_out (capacity) and tile_rows must be the ones the plan was built with. */
 size_t lcf_conv_tile_plan_ints(int k_cap, int kvol, int tile_rows);
 int lcf_conv_tile_rows(int rows);
+int lcf_conv_tile_rows_for(int rows, int kvol, int cin, int cout, int math);
 int lcf_conv_tile_plan(const int *nbr, int k, const int *k_dev, int kvol, int tile_rows, int *plan,
                        void *stream);
 int lcf_indice_conv_fwd_planned(const float *feat, const void *wimg, int math, const int *plan,

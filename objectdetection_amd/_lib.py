@@ -104,6 +104,7 @@ SYMBOLS = {
                                           c_int, _PI3, c_void_p, c_void_p, c_void_p]),
     "lcf_conv_tile_plan_ints": (c_size_t, [c_int, c_int, c_int]),
     "lcf_conv_tile_rows": (c_int, [c_int]),
+    "lcf_conv_tile_rows_for": (c_int, [c_int, c_int, c_int, c_int, c_int]),
     "lcf_conv_tile_plan": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "lcf_indice_conv_fwd_planned": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int,
                                             c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,

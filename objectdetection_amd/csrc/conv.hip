@@ -1308,6 +1308,33 @@ extern "C" size_t lcf_conv_tile_plan_ints(int k_cap, int kvol, int tile_rows)
     return (tiles ? tiles : 1) * (size_t)tc_plan_stride(kvol);
 }
 
+// Tile height of the quad-row form: full 32-row tiles, lower only while that fills three
+// workgroups per CU (18.6k rows: 25-row tiles; in the frame 0.6298 -> 0.6274 ms, 1024 or 1280
+// tiles are no better / worse: tools/ab_env.sh LCF_ENGINE_Q4_FILL at the time)
+static int q4_tile_rows(int rows)
+{
+    const int fixed = lcf_opts().conv_tile;
+    if (fixed >= 16 && fixed <= 32) return fixed;
+    int tr = (rows + 767) / 768;
+    return tr < 16 ? 16 : (tr > 32 ? 32 : tr);
+}
+
+static bool q4_default_for(int kvol, int cin, int cout)
+{
+    const int impl = lcf_opts().conv_impl;
+    return (cin == 32 || cin == 64) && (cout == 32 || cout == 64) &&
+           (impl == 5 || (impl == 0 && kvol >= 9));
+}
+
+extern "C" int lcf_conv_tile_rows_for(int rows, int kvol, int cin, int cout, int math)
+{
+    // the height the default forward of that shape and arithmetic (math as in
+    // lcf_indice_conv_fwd_planned) picks for a launch expecting `rows`
+    LcfCall call(nullptr);
+    if (math == 0 && q4_default_for(kvol, cin, cout)) return q4_tile_rows(rows);
+    return tc_tile_rows(rows);
+}
+
 extern "C" int lcf_conv_tile_rows(int rows)
 {
     // the height the tile-compacted forward picks for a launch that expects `rows` rows
@@ -1438,9 +1465,9 @@ static int cv_launch_tc(const float *feat, const float *wimg, const int *nbr, in
     // quad-row form (conv_q4.h): the default for the 3x3x3 convs of 32 / 64 channels
     if (q4_shape_ok<CIN, COUT>() && cin == CIN && cout == COUT &&
         (op.conv_impl == 5 || (op.conv_impl == 0 && kvol >= 9))) {
-        // full tiles: this form has no per-CU balance to strike (32 rows: 0.6336 -> 0.6292 ms per
-        // frame against the balanced heights, tools/ab_tile.py)
-        const int trq = op.plan ? op.plan_tr : (op.conv_tile ? tr : 32);
+        // its own tile heights (q4_tile_rows): no per-CU balance to strike in this form (32 rows:
+        // 0.6336 -> 0.6292 ms per frame against the balanced heights, tools/ab_tile.py)
+        const int trq = op.plan ? op.plan_tr : q4_tile_rows(rows);
         return cv_launch_q4<CIN, COUT>(feat, wimg, nbr, k_cap, k_dev, kvol, scale, shift, relu,
                                        out, st, trq, dn);
     }

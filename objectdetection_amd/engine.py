@@ -260,12 +260,10 @@ class FrameEngine:
             if l.planned:
                 need = getattr(self, "level_need", None)
                 rows = int(need[lvl]) if need else l.k_out_cap
-                tr = L.lcf_conv_tile_rows(min(rows, l.k_out_cap))
-                # the fp32 3x3x3 convs run the quad-row kernel (csrc/conv_q4.h), which wants full
-                # tiles; the split-operand forms keep the heights balanced over the CUs
-                if not l.x3 and l.kvol >= 9 and l.cin in (32, 64) and l.cout in (32, 64) and \
-                        not os.environ.get("LCF_ENGINE_BALANCED_TILES"):
-                    tr = 32
+                # (the fp32 3x3x3 convs run the quad-row kernel, csrc/conv_q4.h, which cuts its own
+                # tile heights; the split-operand forms keep the heights balanced over the CUs)
+                tr = L.lcf_conv_tile_rows_for(min(rows, l.k_out_cap), l.kvol, l.cin, l.cout,
+                                              (3 if l.planes == 3 else 2) if l.x3 else 0)
                 plan_rows[l.rb_owner.level] = tr
         self.chain = ops.RulebookChain(
             specs, MV, 1, self.sparse_shape, device=dev, plan_rows=plan_rows,

@@ -509,12 +509,17 @@ def conv_forward(features, wimg, nbr, n_rows, kvol, cin, cout, scale=None, shift
     return out
 
 
-def tile_plan(nbr, n_rows, kvol, k_dev=None):
-    """nbr [rows_cap, kvol] -> (plan, tile_rows): the tile-compacted kernels' per-tile set-up for
-    this table (include/lcf.h: lcf_conv_tile_plan), shared by every conv over it."""
+def tile_plan(nbr, n_rows, kvol, k_dev=None, shape=None):
+    """nbr [rows_cap, kvol] -> (plan, tile_rows): the compacted kernels' per-tile set-up for this
+    table (include/lcf.h: lcf_conv_tile_plan), shared by every conv over it.  ``shape`` =
+    (cin, cout, math) of the convs that will read it picks their tile height."""
     _need_cuda(nbr)
     L = _lib.lib()
-    tr = L.lcf_conv_tile_rows(int(n_rows))
+    if shape is not None:
+        tr = L.lcf_conv_tile_rows_for(int(n_rows), int(kvol), int(shape[0]), int(shape[1]),
+                                      int(shape[2]))
+    else:
+        tr = L.lcf_conv_tile_rows(int(n_rows))
     plan = torch.zeros(L.lcf_conv_tile_plan_ints(int(n_rows), int(kvol), tr), dtype=torch.int32,
                        device=nbr.device)
     check(L.lcf_conv_tile_plan(_ptr(nbr), int(n_rows), _ptr(k_dev), int(kvol), tr, _ptr(plan),

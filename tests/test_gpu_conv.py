@@ -377,7 +377,7 @@ def test_quad_row_form_matches_oracle(oracle, cuda, cin, cout, sets, tile, subm)
         again = ops.conv_forward(xt, img, rb.out_nbr, rb.k_out, 27, cin, cout)
         # a capacity with the count on the device, through a tile plan
         cap = k_out + 333
-        tr = tile if tile else L.lcf_conv_tile_rows(k_out)
+        tr = tile if tile else L.lcf_conv_tile_rows_for(k_out, 27, cin, cout, 0)
         nbr = torch.cat([rb.out_nbr, torch.full((333, 27), 5, dtype=torch.int32, device=cuda)])
         k_dev = torch.tensor([k_out], dtype=torch.int32, device=cuda)
         plan = torch.zeros(L.lcf_conv_tile_plan_ints(cap, 27, tr), dtype=torch.int32, device=cuda)
@@ -395,10 +395,7 @@ def test_quad_row_form_matches_oracle(oracle, cuda, cin, cout, sets, tile, subm)
         L.lcf_set_option(_lib.OPT_CONV_TILE, 0)
     assert rel_err(out.cpu().numpy(), ref) < RTOL
     assert torch.equal(out, again)
-    if tile:  # (tile 0: the heights the two calls pick from their row counts may differ)
-        assert torch.equal(planned[:k_out], out)
-    else:
-        assert rel_err(planned[:k_out].cpu().numpy(), ref) < RTOL
+    assert torch.equal(planned[:k_out], out)
     assert bool((planned[k_out:] == 7.0).all())
 
 
@@ -787,8 +784,8 @@ def test_planned_forward_is_bit_identical_to_the_table_forward(cuda, math):
         st = torch.cuda.current_stream().cuda_stream
         for cap_extra in (0, 777):  # exact row count, and a capacity with the count on the device
             cap = k + cap_extra
-            # (fp32: these shapes run the quad-row kernel, whose table forward cuts 32-row tiles)
-            tr = 32 if math == 0 else L.lcf_conv_tile_rows(k)
+            # (the height the table forward of that shape and arithmetic cuts)
+            tr = L.lcf_conv_tile_rows_for(k, kvol, cin, cout, math)
             nbr = torch.cat([rb.out_nbr, torch.full((cap_extra, kvol), 5, dtype=torch.int32,
                                                     device=cuda)])
             k_dev = torch.tensor([k], dtype=torch.int32, device=cuda)
