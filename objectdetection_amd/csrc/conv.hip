@@ -1308,6 +1308,10 @@ extern "C" size_t lcf_conv_tile_plan_ints(int k_cap, int kvol, int tile_rows)
     return (tiles ? tiles : 1) * (size_t)tc_plan_stride(kvol);
 }
 
+// fewer offsets than this: the tile-compacted kernel (the 3-offset conv in front of dense():
+// 0.627 -> 0.631 ms per frame on the quad-row form, tools/ab_lib.sh)
+#define Q4_KVOL_MIN 9
+
 // Tile height of the quad-row form: full 32-row tiles, lower only while that fills three
 // workgroups per CU (18.6k rows: 25-row tiles; in the frame 0.6298 -> 0.6274 ms, 1024 or 1280
 // tiles are no better / worse: tools/ab_env.sh LCF_ENGINE_Q4_FILL at the time)
@@ -1323,7 +1327,7 @@ static bool q4_default_for(int kvol, int cin, int cout)
 {
     const int impl = lcf_opts().conv_impl;
     return (cin == 32 || cin == 64) && (cout == 32 || cout == 64) &&
-           (impl == 5 || (impl == 0 && kvol >= 9));
+           (impl == 5 || (impl == 0 && kvol >= Q4_KVOL_MIN));
 }
 
 extern "C" int lcf_conv_tile_rows_for(int rows, int kvol, int cin, int cout, int math)
@@ -1464,7 +1468,7 @@ static int cv_launch_tc(const float *feat, const float *wimg, const int *nbr, in
     const int tr = tc_tile_rows(rows);
     // quad-row form (conv_q4.h): the default for the 3x3x3 convs of 32 / 64 channels
     if (q4_shape_ok<CIN, COUT>() && cin == CIN && cout == COUT &&
-        (op.conv_impl == 5 || (op.conv_impl == 0 && kvol >= 9))) {
+        (op.conv_impl == 5 || (op.conv_impl == 0 && kvol >= Q4_KVOL_MIN))) {
         // its own tile heights (q4_tile_rows): no per-CU balance to strike in this form (32 rows:
         // 0.6336 -> 0.6292 ms per frame against the balanced heights, tools/ab_tile.py)
         const int trq = op.plan ? op.plan_tr : q4_tile_rows(rows);
