@@ -422,6 +422,38 @@ def main(argv=None):
                             "tolerance": 1e-4})
                 del eng3
 
+        # throughput with two batch-1 frames in flight (never `value`, which stays the one-frame-
+        # at-a-time rate every round has reported): a second engine with its own buffers and graph
+        # on a second stream, frames alternating over the two
+        pipelined = None
+        if (world == 1 and not args.eager and not args.no_alt and args.inflight == 1
+                and args.model != "M3"):
+            eng2 = model.engine(calib=calib, conv_math=args.conv_math)
+            pair = [(engine, torch.cuda.Stream(device=dev)), (eng2, torch.cuda.Stream(device=dev))]
+
+            def step2(i):
+                e, st = pair[i % 2]
+                with torch.cuda.stream(st):
+                    return e.forward(clouds[i % len(clouds)])
+            for i in range(args.warmup):
+                step2(i)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for i in range(args.steps):
+                out2 = step2(i)
+            torch.cuda.synchronize()
+            el2 = time.perf_counter() - t1
+            engine.check()
+            eng2.check()
+            err2 = ((out2 - ref).abs().max() / ref.abs().max()).item()
+            assert err2 < 1e-4, f"pipelined engine output differs from the module path: {err2}"
+            pipelined = {"frames_in_flight": 2, "value": round(args.steps / el2, 2),
+                         "unit": "frames/s", "ms_per_frame": round(el2 / args.steps * 1e3, 4),
+                         "note": "two FrameEngines (own buffers, own graph) on two streams, "
+                                 "frames alternating; same kernels, same results; a frame's "
+                                 "latency is then about twice ms_per_frame"}
+            del eng2
+
     train = train_measurement(args, dev, rank, world, dist, barrier) if args.train_steps > 0 \
         and args.model != "M3" else None
 
@@ -451,6 +483,8 @@ def main(argv=None):
             line["roofline"] = roof
         if alt is not None:
             line["alt"] = alt
+        if pipelined is not None:
+            line["pipelined"] = pipelined
         if train is not None:
             line["train"] = train
         if world == 1 and not args.eager and not args.no_alt:
