@@ -148,6 +148,17 @@ class VoxelGeneratorV2:
 
     def _run(self, points, max_voxels):
         pts = np.ascontiguousarray(points, dtype=np.float32)
+        if self._device is not None and torch.device(self._device).type == "cpu":
+            # asked for by name (device="cpu"): the GPU-free twin, for forked DataLoader workers
+            # (objectdetection_amd/cpu.py; same results as the HIP voxelizer, bit for bit)
+            if self._full_mean:
+                raise NotImplementedError("full_mean is not part of the CPU twin")
+            from .. import cpu
+            v, c, n, k = cpu.voxelize(pts, self._voxel_size, self._point_cloud_range,
+                                      self._max_num_points, int(max_voxels or self._max_voxels),
+                                      self._cap_mode)
+            return {"voxels": torch.from_numpy(v), "coordinates": torch.from_numpy(c),
+                    "num_points_per_voxel": torch.from_numpy(n)}, k
         res = self.generate_device(torch.from_numpy(pts).to(self._dev()), max_voxels)
         k = int(res["voxel_num"].item())
         return res, k

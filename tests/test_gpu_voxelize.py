@@ -115,3 +115,19 @@ def test_generator_api(oracle, cuda):
                               np.array(synth.PC_RANGE, np.float32), 5, reverse_index=True,
                               max_voxels=17000)
     assert np.array_equal(v, ev) and np.array_equal(c, ec) and np.array_equal(n, en)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cap_mode,max_vox", [(0, 40000), (0, 2500), (1, 2500)])
+def test_cpu_twin_equals_the_hip_voxelizer(cuda, cap_mode, max_vox):
+    """include/lcf_cpu.h: the GPU-free twin for forked DataLoader workers gives what the HIP
+    voxelizer gives, bit for bit, padding rows included."""
+    from objectdetection_amd import cpu, ops, synth
+    pts = synth.vkitti_frame(21, 20000)
+    v, c, n, k = cpu.voxelize(pts, synth.VOXEL_SIZE, synth.PC_RANGE, 5, max_vox, cap_mode,
+                              batch_idx=1)
+    gv, gc, gn, gk = ops.voxelize(torch.from_numpy(pts).to(cuda), synth.VOXEL_SIZE, synth.PC_RANGE,
+                                  5, max_vox, cap_mode, batch_idx=1)
+    assert int(gk.item()) == k
+    assert np.array_equal(gv.cpu().numpy(), v) and np.array_equal(gn.cpu().numpy(), n)
+    assert np.array_equal(gc.cpu().numpy()[:k], c[:k])
