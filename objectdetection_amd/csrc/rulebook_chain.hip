@@ -464,6 +464,11 @@ extern "C" int lcf_rulebook_chain_parts(const int *coors, int k, const int *k_de
     if (ws0_bytes < lcf_rulebook_subm_workspace_bytes(k)) return LCF_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     const bool unfused = ctx && ctx->o.rb_unfused;
+    // strided levels (from the first) whose own table is launched ahead of the rest of launch X:
+    // all of them (in the frame 0.627 -> 0.616 ms with the first, 0.613-0.616 with all, A/B in one
+    // call; LCF_RB_SPLIT_FILL=0 in the environment restores the single launch)
+    static const int split_fill =
+        getenv("LCF_RB_SPLIT_FILL") ? atoi(getenv("LCF_RB_SPLIT_FILL")) : 64;
 
     // ---- plan: geometry and workspace of every level, validated before anything is enqueued
     RbcPlanLevel plan[64];
@@ -707,6 +712,18 @@ extern "C" int lcf_rulebook_chain_parts(const int *coors, int k, const int *k_de
             RbcLaunch L{};
             unsigned blocks = 0;
             add_lookup(L, blocks, nxt, cur, plan[s], lv[s].out_nbr, true, lv[s]);
+            // The strided conv's own table is what the feature path needs first: for the leading
+            // levels, where that path runs right behind the chain, it goes out as a launch of its
+            // own (and its event is recorded) ahead of the new level's look-ups.
+            bool fill_alone = part - 1 < split_fill;
+            if (fill_alone) {
+                int rc = on() ? rbc_launch(L, blocks, st, 3, unfused) : LCF_OK;
+                if (rc) return rc;
+                rc = record(s);
+                if (rc) return rc;
+                L = RbcLaunch{};
+                blocks = 0;
+            }
             int j = s + 1;
             while (j < s2 && L.n < RBC_MAX_ROLES - (s2 < n ? 1 : 0)) {
                 add_lookup(L, blocks, nxt, nxt, plan[j], lv[j].out_nbr, false, lv[j]);
@@ -715,7 +732,7 @@ extern "C" int lcf_rulebook_chain_parts(const int *coors, int k, const int *k_de
             if (s2 < n) add_ins64(L, blocks, nxt, plan[s2]);
             int rc = on() ? rbc_launch(L, blocks, st, 3, unfused) : LCF_OK;
             if (rc) return rc;
-            for (int q = s; q < j; ++q) {
+            for (int q = fill_alone ? s + 1 : s; q < j; ++q) {
                 rc = record(q);
                 if (rc) return rc;
             }
