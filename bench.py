@@ -428,31 +428,26 @@ def main(argv=None):
         pipelined = None
         if (world == 1 and not args.eager and not args.no_alt and args.inflight == 1
                 and args.model != "M3"):
-            eng2 = model.engine(calib=calib, conv_math=args.conv_math)
-            pair = [(engine, torch.cuda.Stream(device=dev)), (eng2, torch.cuda.Stream(device=dev))]
-
-            def step2(i):
-                e, st = pair[i % 2]
-                with torch.cuda.stream(st):
-                    return e.forward(clouds[i % len(clouds)])
+            from objectdetection_amd.engine import FramePipeline
+            pipe = FramePipeline(model, calib=calib, depth=2, conv_math=args.conv_math)
             for i in range(args.warmup):
-                step2(i)
+                pipe.submit(clouds[i % len(clouds)], wait_current=False)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             for i in range(args.steps):
-                out2 = step2(i)
+                out2, _ = pipe.submit(clouds[i % len(clouds)], wait_current=False)
             torch.cuda.synchronize()
             el2 = time.perf_counter() - t1
-            engine.check()
-            eng2.check()
+            pipe.check()
             err2 = ((out2 - ref).abs().max() / ref.abs().max()).item()
             assert err2 < 1e-4, f"pipelined engine output differs from the module path: {err2}"
             pipelined = {"frames_in_flight": 2, "value": round(args.steps / el2, 2),
                          "unit": "frames/s", "ms_per_frame": round(el2 / args.steps * 1e3, 4),
-                         "note": "two FrameEngines (own buffers, own graph) on two streams, "
-                                 "frames alternating; same kernels, same results; a frame's "
-                                 "latency is then about twice ms_per_frame"}
-            del eng2
+                         "note": "objectdetection_amd.engine.FramePipeline: two FrameEngines (own "
+                                 "buffers, own graph) on two streams, frames alternating; same "
+                                 "kernels, same results; a frame's latency is then about twice "
+                                 "ms_per_frame"}
+            del pipe
 
     train = train_measurement(args, dev, rank, world, dist, barrier) if args.train_steps > 0 \
         and args.model != "M3" else None

@@ -323,3 +323,33 @@ def test_overflow_replan_is_bounded_and_uses_observed_counts(cuda):
     assert all(a >= b for a, b in zip(eng.level_caps, before)) and eng.level_caps != before
     assert eng.level_need[0] > 20000
     assert ((out - ref).abs().max() / ref.abs().max()).item() < 1e-5
+
+
+@pytest.mark.gpu
+def test_frame_pipeline_gives_each_frame_the_single_engine_result(cuda):
+    """FramePipeline: frames dealt over two engines on two streams come out as the one-engine
+    path computes them, bit for bit, whatever is in flight beside them."""
+    from objectdetection_amd.engine import FramePipeline
+    model = randomize_(SparseFrontEnd("M2").eval(), 0).to(cuda)
+    calib = _clouds(cuda, [0, 1], 20000)
+    with torch.no_grad():
+        eng = model.engine(calib=calib)
+        pipe = FramePipeline(model, calib=calib, depth=2)
+        frames = [torch.from_numpy(synth.vkitti_frame(s, n)).to(cuda)
+                  for s, n in [(3, 20000), (4, 9000), (5, 20000), (6, 15000), (3, 20000)]]
+        torch.cuda.synchronize()
+        outs = []
+        for c in frames:
+            out, done = pipe.submit(c)
+            outs.append((out, done))
+            if len(outs) >= 2:  # consume a result before its slot is used again
+                o, ev = outs[-2]
+                ev.synchronize()
+                outs[-2] = o.clone()
+        pipe.synchronize()
+        outs[-1] = outs[-1][0].clone()
+        pipe.check()
+        for c, o in zip(frames, outs):
+            ref = eng.forward(c).clone()
+            eng.check()
+            assert torch.equal(o, ref)
