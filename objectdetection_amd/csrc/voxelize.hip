@@ -39,10 +39,16 @@ __global__ void __launch_bounds__(VOX_BLOCK)
 vox_insert_kernel(const float *__restrict__ pts, int n_begin, int n_cap,
                   const int *__restrict__ n_dev, int f, VoxParams p, int max_pts,
                   uint32_t *__restrict__ keys, uint32_t mask, int *__restrict__ lists,
-                  int *__restrict__ cellslot)
+                  int *__restrict__ cellslot, int *__restrict__ scan_state, int scan_nblk,
+                  int *__restrict__ ctrl)
 {
     const int n = lcf_count(n_cap, n_dev);
-    int i = n_begin + blockIdx.x * VOX_BLOCK + threadIdx.x;
+    // what vox_scan_kernel (next launch) expects: its per-block states at 0, and i* = "never" at
+    // the start of a session
+    const int gid = blockIdx.x * VOX_BLOCK + threadIdx.x;
+    if (gid < scan_nblk) scan_state[gid] = 0;
+    if (gid == 0 && n_begin == 0) ctrl[0] = 0x7FFFFFFF;
+    int i = n_begin + gid;
     if (i >= n) return;
     int c[3];
     bool ok = true;
@@ -136,6 +142,95 @@ vox_assign_kernel(const int *__restrict__ cellslot, const int *__restrict__ list
         }
     }
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+        int nfirst = blockbase + total;
+        ctrl[1] = nfirst;
+        voxel_num[0] = nfirst < max_vox ? nfirst : max_vox;
+    }
+}
+
+// vox_count_kernel + vox_assign_kernel as ONE launch (decoupled look-back over the per-block
+// counts: a block publishes its count, adds up what its predecessors published -- blocks are
+// dispatched in index order and publish before they wait -- and hands out the ids; the same ids
+// as the two-launch form).  state[b] = status << 30 | value: 0 nothing yet (cleared by
+// vox_insert_kernel, one launch earlier), 1 the block's own count, 2 the count up to and
+// including b (block 0: on top of the first points of the earlier calls of the session).  A wait
+// that does not end within VOX_SPIN_LIMIT polls gives up (the ids are then wrong, the call does
+// not hang).  The voxelizer is the head of a frame's critical path: one launch less is 5 us.
+#define VOX_SPIN_LIMIT (1 << 22)
+__global__ void __launch_bounds__(VOX_BLOCK)
+vox_scan_kernel(const int *__restrict__ cellslot, const int *__restrict__ lists, int max_pts,
+                int n_begin, int n_cap, const int *__restrict__ n_dev, int *__restrict__ bsums,
+                int max_vox, int *__restrict__ pvid, int *__restrict__ ctrl,
+                int *__restrict__ voxel_num, int init_istar)
+{
+    __shared__ int lds[8];
+    const int n = lcf_count(n_cap, n_dev);
+    const int blk = blockIdx.x;
+    int base = n_begin + (blk * VOX_BLOCK + threadIdx.x) * VOX_ITEMS;
+    int fl[VOX_ITEMS];
+    int cnt = 0;
+#pragma unroll
+    for (int j = 0; j < VOX_ITEMS; ++j) {
+        fl[j] = vox_is_first(cellslot, lists, max_pts, base + j, n);
+        cnt += fl[j];
+    }
+    int total;
+    int ex = lcf_block_excl_scan_256(cnt, lds, &total);
+    unsigned *state = reinterpret_cast<unsigned *>(bsums);
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        int sum = 0;
+        if (blk == 0) {
+            // ctrl[0] = i*, ctrl[1] = first points so far, ctrl[2] = that count before this call
+            if (lane == 0) {
+                sum = n_begin == 0 ? 0 : ctrl[1];
+                ctrl[2] = sum;
+                if (init_istar) ctrl[0] = 0x7FFFFFFF; // (no insert launch ran: nothing races)
+                atomicExch(&state[0], (2u << 30) | (unsigned)(sum + total));
+            }
+            sum = __shfl(sum, 0, 64);
+        } else {
+            if (lane == 0) atomicExch(&state[blk], (1u << 30) | (unsigned)total);
+            int pos = blk - 1, polls = 0;
+            bool done = false;
+            while (!done) {
+                const int idx = pos - lane;
+                unsigned v = 2u << 30;
+                if (idx >= 0)
+                    v = __hip_atomic_load(&state[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned stt = v >> 30;
+                if (__ballot(stt == 0u) != 0ull) {
+                    if (++polls > VOX_SPIN_LIMIT) done = true;
+                    __builtin_amdgcn_s_sleep(1);
+                    continue;
+                }
+                const unsigned long long full = __ballot(stt == 2u);
+                const int first = full ? __builtin_ctzll(full) : 64;
+                int val = lane <= first ? (int)(v & 0x3FFFFFFFu) : 0;
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) val += __shfl_xor(val, d, 64);
+                sum += val;
+                if (full)
+                    done = true;
+                else
+                    pos -= 64;
+            }
+            if (lane == 0) atomicExch(&state[blk], (2u << 30) | (unsigned)(sum + total));
+        }
+        if (lane == 0) lds[4] = sum;
+    }
+    __syncthreads();
+    const int blockbase = lds[4];
+    ex += blockbase;
+#pragma unroll
+    for (int j = 0; j < VOX_ITEMS; ++j) {
+        if (fl[j]) {
+            pvid[base + j] = ex;
+            if (ex == max_vox) ctrl[0] = base + j; // unique writer: the sequential loop stops here
+            ++ex;
+        }
+    }
+    if (blk == (int)gridDim.x - 1 && threadIdx.x == 0) {
         int nfirst = blockbase + total;
         ctrl[1] = nfirst;
         voxel_num[0] = nfirst < max_vox ? nfirst : max_vox;
@@ -295,16 +390,26 @@ static int vox_run(const float *points, int n, const int *n_dev, int f, const fl
     const int n_new = n - n_begin;
     int nblk = (n_new + VOX_BLOCK * VOX_ITEMS - 1) / (VOX_BLOCK * VOX_ITEMS);
     if (nblk < 1) nblk = 1;
+    // LCF_VOX_TWO_PASS (environment, A/B and fallback): count and assign as two launches
+    static const bool two_pass = getenv("LCF_VOX_TWO_PASS") != nullptr;
     if (n_new > 0) {
         vox_insert_kernel<<<(n_new + VOX_BLOCK - 1) / VOX_BLOCK, VOX_BLOCK, 0, st>>>(
-            points, n_begin, n, n_dev, f, p, max_pts, w.keys, w.hc - 1, w.lists, w.cellslot);
+            points, n_begin, n, n_dev, f, p, max_pts, w.keys, w.hc - 1, w.lists, w.cellslot,
+            w.bsums, two_pass ? 0 : nblk, w.ctrl);
         LCF_CHECK_LAUNCH();
     }
-    vox_count_kernel<<<nblk, VOX_BLOCK, 0, st>>>(w.cellslot, w.lists, max_pts, n_begin, n, n_dev,
-                                                 w.bsums, w.ctrl);
-    LCF_CHECK_LAUNCH();
-    vox_assign_kernel<<<nblk, VOX_BLOCK, 0, st>>>(w.cellslot, w.lists, max_pts, n_begin, n, n_dev,
-                                                  w.bsums, max_vox, w.pvid, w.ctrl, voxel_num);
+    if (two_pass) {
+        vox_count_kernel<<<nblk, VOX_BLOCK, 0, st>>>(w.cellslot, w.lists, max_pts, n_begin, n,
+                                                     n_dev, w.bsums, w.ctrl);
+        LCF_CHECK_LAUNCH();
+        vox_assign_kernel<<<nblk, VOX_BLOCK, 0, st>>>(w.cellslot, w.lists, max_pts, n_begin, n,
+                                                      n_dev, w.bsums, max_vox, w.pvid, w.ctrl,
+                                                      voxel_num);
+    } else {
+        vox_scan_kernel<<<nblk, VOX_BLOCK, 0, st>>>(w.cellslot, w.lists, max_pts, n_begin, n, n_dev,
+                                                    w.bsums, max_vox, w.pvid, w.ctrl, voxel_num,
+                                                    n_new > 0 ? 0 : (n_begin == 0 ? 1 : 0));
+    }
     LCF_CHECK_LAUNCH();
     int m = n_begin == 0 && max_vox > n_new ? max_vox : n_new;
     if (m > 0) {
