@@ -43,9 +43,7 @@ def main():
                                conv.weight))
             x = conv(x, _scale=scale, _shift=shift, _relu=True)
     torch.cuda.synchronize()
-    variants = [("tc", 2, 0), ("q4x2", 5, 2), ("q4x4", 5, 4), ("q4x3k3", 5, 4), ("q4x4k2", 5, 4)]
-    for ab in [int(a) for a in os.environ.get("Q4_ABLATES", "").split(",") if a]:
-        variants.append((f"q4x4_ab{ab}", 5, 4))
+    variants = [("tc", 2, 0), ("q4x1", 5, 1), ("q4x2", 5, 2), ("q4x3", 5, 3), ("q4x4", 5, 4)]
     tiles = [0] + [int(t) for t in os.environ.get("Q4_TILES", "").split(",") if t]
     reps, rounds = 10, 5
     res = {}
@@ -55,8 +53,6 @@ def main():
                 L.lcf_set_option(1, impl)
                 L.lcf_set_option(3, sets)
                 L.lcf_set_option(2, tile)
-                os.environ["LCF_Q4_ABLATE"] = vname.split("_ab")[1] if "_ab" in vname else "0"
-                os.environ["LCF_Q4_KS"] = "2" if "k2" in vname else ("3" if "k3" in vname else "1")
                 for li, (name, args, pairs, w) in enumerate(layers):
                     ops.conv_forward(*args)
                     e0 = torch.cuda.Event(enable_timing=True)
@@ -90,10 +86,7 @@ def main():
         ref = torch.relu(ref * scale.double() + shift.double())
         e = lambda t: float((t.double() - ref).abs().max() / ref.abs().max())
         row = f"err vs f64 {name:40s}"
-        os.environ["LCF_Q4_ABLATE"] = "0"
         for vname, impl, sets in variants:
-            if "_ab" in vname:
-                continue
             L.lcf_set_option(1, impl)
             L.lcf_set_option(3, sets)
             L.lcf_set_option(2, 0)
