@@ -90,7 +90,6 @@ def main():
             L.lcf_set_option(1, impl)
             L.lcf_set_option(3, sets)
             L.lcf_set_option(2, 0)
-            os.environ["LCF_Q4_KS"] = "2" if "k2" in vname else ("3" if "k3" in vname else "1")
             a = ops.conv_forward(*args)
             b = ops.conv_forward(*args)
             row += f" {vname} {e(a):.2e}{'' if torch.equal(a, b) else ' NONDET'}"
