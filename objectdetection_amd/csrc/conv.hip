@@ -1467,8 +1467,7 @@ static int cv_launch_tc(const float *feat, const float *wimg, const int *nbr, in
     const int rows = op.rows_hint > 0 && op.rows_hint < k_cap ? op.rows_hint : k_cap;
     const int tr = tc_tile_rows(rows);
     // quad-row form (conv_q4.h): the default for the 3x3x3 convs of 32 / 64 channels
-    if (q4_shape_ok<CIN, COUT>() && cin == CIN && cout == COUT &&
-        (op.conv_impl == 5 || (op.conv_impl == 0 && kvol >= Q4_KVOL_MIN))) {
+    if (q4_shape_ok<CIN, COUT>() && cin == CIN && cout == COUT && q4_default_for(kvol, cin, cout)) {
         // its own tile heights (q4_tile_rows): no per-CU balance to strike in this form (32 rows:
         // 0.6336 -> 0.6292 ms per frame against the balanced heights, tools/ab_tile.py)
         const int trq = op.plan ? op.plan_tr : q4_tile_rows(rows);
