@@ -60,7 +60,7 @@ class SparseFrontEnd(nn.Module):
             return vs[0], ns[0], cs[0]
         return torch.cat(vs), torch.cat(ns), torch.cat(cs)
 
-    def engine(self, calib=None, max_points=None, margin=1.5, use_graph=True, two_streams=True,
+    def engine(self, calib=None, max_points=None, margin=2.0, use_graph=True, two_streams=True,
                conv_math="f32"):
         """Batch-1 inference engine: the whole frame as one hipGraph replay without host
         synchronisation (objectdetection_amd/engine.py).  ``calib``: sample clouds that size it."""
