@@ -353,3 +353,29 @@ def test_frame_pipeline_gives_each_frame_the_single_engine_result(cuda):
             ref = eng.forward(c).clone()
             eng.check()
             assert torch.equal(o, ref)
+
+
+@pytest.mark.gpu
+def test_frame_batch_rows_are_the_models_batch_rows():
+    """FrameBatch (B engines writing the B slices of one dense buffer) against the eager module
+    on the same batch of clouds, and row b against a single FrameEngine on cloud b."""
+    from objectdetection_amd.engine import FrameBatch, FrameEngine
+    dev = torch.device("cuda:0")
+    model = randomize_(SparseFrontEnd("M2").eval(), 3).to(dev)
+    clouds = [torch.from_numpy(synth.vkitti_frame(i, n)).to(dev) for i, n in ((0, 9000), (1, 6000))]
+    eng = FrameBatch(model, batch=2, calib=clouds)
+    out = eng(clouds).clone()
+    eng.check()
+    with torch.no_grad():
+        ref = model(clouds)
+    assert out.shape == ref.shape and out.shape[0] == 2
+    scale = float(ref.abs().max())
+    assert float((out - ref).abs().max()) <= 1e-4 * scale
+    single = FrameEngine(model, calib=clouds)
+    for b, c in enumerate(clouds):
+        assert torch.equal(single(c), out[b:b + 1])
+    # a second call, clouds swapped: each slot re-arms its own workspaces
+    out2 = eng(clouds[::-1]).clone()
+    assert torch.equal(out2[0], out[1]) and torch.equal(out2[1], out[0])
+    with pytest.raises(ValueError):
+        eng(clouds[:1])
