@@ -34,13 +34,17 @@ def durs(path):
 
 def main():
     tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
-    f = load("gpurun_out/pmc_fetch/p_counter_collection.csv")
-    w = load("gpurun_out/pmc_write/p_counter_collection.csv")
-    s = load("gpurun_out/pmc_sq/p_counter_collection.csv")
-    du = durs("gpurun_out/pmc_sq/p_kernel_trace.csv")
+    # "train": the passes of tools/profile_train.sh over the batch-8 training step (every kernel
+    # of the step, library GEMMs and torch's elementwise kernels included)
+    train = len(sys.argv) > 2 and sys.argv[2] == "train"
+    base = f"gpurun_out/{tag}_train/" if train else "gpurun_out/"
+    f = load(base + "pmc_fetch/p_counter_collection.csv")
+    w = load(base + "pmc_write/p_counter_collection.csv")
+    s = load(base + "pmc_sq/p_counter_collection.csv")
+    du = durs(base + "pmc_sq/p_kernel_trace.csv")
     rows = []
     for k in sorted(s, key=lambda k: -sum(du.get(k, [0]))):
-        if "at::" in k or "rocclr" in k or "Cijk" in k:
+        if not train and ("at::" in k or "rocclr" in k or "Cijk" in k):
             continue
         fe = st.mean(f[k]["FETCH_SIZE"]) * 1024 if k in f else 0
         wr = st.mean(w[k]["WRITE_SIZE"]) * 1024 if k in w else 0
@@ -57,12 +61,17 @@ def main():
             mfma_util=round(sq.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / (cyc * 1024), 4) if cyc else 0,
             wait_any_frac=round(sq["SQ_WAIT_ANY"] / wc, 3) if wc else 0,
             wait_inst_frac=round(sq["SQ_WAIT_INST_ANY"] / wc, 3) if wc else 0))
-    with open(f"profiles/{tag}_pmc_summary.csv", "w") as fo:
+    with open(f"profiles/{tag}{'_train' if train else ''}_pmc_summary.csv", "w") as fo:
         wri = csv.DictWriter(fo, fieldnames=list(rows[0].keys()))
         wri.writeheader()
         wri.writerows(rows)
     # the dominant kernel of bench.py: the 3x3x3 64->64 forward (quad-row form; before round 2's
     # end the tile-compacted one, one or two wave sets)
+    if train:
+        for r in rows[:40]:
+            print(f"{r['kernel'][:60]:60s} x{r['launches']:4d} {r['avg_us']:8.2f} us  "
+                  f"{r['hbm_GBps']:8.1f} GB/s  mfma_util {r['mfma_util']}")
+        return
     tc = [r for r in rows if r["kernel"].startswith("cv_q4_kernel<64, 64")]
     name = "cv_q4_kernel<64,64,4>"
     if not tc:

@@ -22,6 +22,8 @@ for i in range(steps):
     step(frames[8 * (i % 2):8 * (i % 2) + 8])
 torch.cuda.synchronize()
 print("ms/step", (time.perf_counter() - t0) / steps * 1e3)
+if len(sys.argv) > 2 and sys.argv[2] == "pmc":  # a counter pass: the steady-state steps only
+    sys.exit(0)
 
 # wall-clock breakdown of one step (synchronised between sections)
 def sect(fn):
