@@ -9,7 +9,7 @@ steps=${2:-12}
 out=gpurun_out/${tag}_train
 mkdir -p $out profiles
 export TMPDIR=/tmp
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -o p -- python3 tools/prof_train.py $steps > $out/kt.log 2>&1
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -o p -- python3 tools/prof_train.py $steps pmc > $out/kt.log 2>&1
 echo "train kernel trace done"
 timeout -s KILL 240 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -o p -- python3 tools/prof_train.py 2 pmc > $out/pmc_fetch.log 2>&1
 echo "train pmc fetch done"
