@@ -131,6 +131,15 @@ int lcf_voxelize(const float *points, int n, const int *n_dev, int f, const floa
                  const float range[6], int max_pts, int max_vox, int cap_mode, int batch_idx,
                  int coor_stride, float *voxels, int *coors, int *num_pts, int *voxel_num,
                  void *ws, size_t ws_bytes, void *stream, lcf_ctx *ctx);
+/* Diagnostics of the one-launch count + assign step (a decoupled look-back scan): a block that
+ * waits too long for a predecessor's count (HIP does not promise dispatch in index order) counts
+ * the first points in front of it itself -- the outputs are right either way -- and bumps a
+ * counter in the workspace, cleared when a call (or an appending session) starts.  This returns
+ * the counter's DEVICE address inside `ws` (one int); a non-zero value means frames ran the slow
+ * way.  LCF_VOX_SPIN_LIMIT (environment) sets the polls waited, LCF_VOX_TWO_PASS selects the
+ * two-launch form.  No counterpart in the reference. */
+int lcf_voxelize_scan_fallbacks(void *ws, size_t ws_bytes, int n, int max_pts,
+                                const int **counter_dev);
 
 /* lcf_voxelize without a workspace argument, for callers that CANNOT ALLOCATE device memory (code
  * under hipGraph capture, tight serving loops, harnesses that forbid hipMalloc).  No counterpart
@@ -405,6 +414,19 @@ int lcf_fill_u32(void *p, uint32_t value, size_t bytes, void *stream, lcf_ctx *c
  */
 int lcf_dense(const float *feat, const int *coors, int k, const int *k_dev, int c, int batch,
               const int shape[3], int zero_fill, float *out, void *stream);
+/* Rows-only clear of a dense() output that is re-used frame after frame (SURVEY.md section 8f-1;
+ * the reference's dense() allocates and zero-fills the whole [B,C,D,H,W] tensor per call,
+ * second/pytorch/models/middle.py:206 -> torchplus/ops/array_ops.py:7-18).  `prev_coors` [cap,4]
+ * i32 is caller-owned state: the (b,z,y,x) the previous frame's rows were scattered to, -1 rows =
+ * none (initialise to -1 together with a zeroed `dense`).  The call zeroes dense[b,:,z,y,x] for
+ * every row of prev_coors, then sets prev_coors = coors[0 : k] (-1 beyond k; k = *k_dev clamped
+ * to cap, or cap when k_dev is NULL) -- the rows the caller is about to scatter.  Afterwards
+ * `dense` is all zero again provided every earlier scatter went through this bookkeeping.  With
+ * an open fill batch on `ctx` the call is recorded (one per batch) and runs inside the flush's
+ * launch; otherwise it is one launch on `stream`.  c = channels, shape = (D,H,W). */
+int lcf_dense_clear_rows(float *dense, int *prev_coors, const int *coors, int cap,
+                         const int *k_dev, int c, int batch, const int shape[3], void *stream,
+                         lcf_ctx *ctx);
 int lcf_dense_bwd(const float *dout, const int *coors, int k, int c, int batch,
                   const int shape[3], float *dfeat, void *stream);
 

@@ -46,6 +46,8 @@ SYMBOLS = {
     "lcf_voxelize_append": (c_int, [c_void_p, c_int, c_int, c_int, c_int, _PF, _PF, c_int, c_int,
                                     c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_void_p, c_size_t, c_void_p, c_void_p]),
+    "lcf_voxelize_scan_fallbacks": (c_int, [c_void_p, c_size_t, c_int, c_int,
+                                            ctypes.POINTER(c_void_p)]),
     "lcf_voxelize_static_max_bytes": (c_size_t, []),
     "lcf_voxelize_static": (c_int, [c_void_p, c_int, c_void_p, c_int, _PF, _PF, c_int, c_int,
                                     c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
@@ -118,6 +120,8 @@ SYMBOLS = {
     "lcf_load_points": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     "lcf_dense": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, _PI3, c_int,
                           c_void_p, c_void_p]),
+    "lcf_dense_clear_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int,
+                                     _PI3, c_void_p, c_void_p]),
     "lcf_dense_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, _PI3, c_void_p,
                               c_void_p]),
     "lcf_vfe_affine_relu_segmax_fwd": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p,
@@ -172,7 +176,8 @@ CTX_LAST = {"lcf_voxelize", "lcf_voxelize_append", "lcf_voxelize_workspace_reset
             "lcf_rulebook_conv_discover", "lcf_rulebook_conv_fill", "lcf_indice_conv_fwd",
             "lcf_indice_conv_fwd_bf16", "lcf_indice_conv_fwd_bf16x3",
             "lcf_indice_conv_fwd_bf16x8", "lcf_indice_conv_fwd_dense", "lcf_fill_u32",
-            "lcf_rulebook_chain", "lcf_rulebook_chain_parts", "lcf_rulebook_chain_reset", "lcf_indice_conv_fwd_planned"}
+            "lcf_rulebook_chain", "lcf_rulebook_chain_parts", "lcf_rulebook_chain_reset", "lcf_indice_conv_fwd_planned",
+            "lcf_dense_clear_rows"}
 
 
 class _Lib:

@@ -37,8 +37,20 @@ struct LcfFillSeg {
     unsigned blk0; // first workgroup of the segment
     unsigned long long n32;
 };
+// one optional "clear the rows the previous frame wrote" record per batch (lcf_dense_clear_rows):
+// the workgroups from blk0 on zero dense[b, :, z, y, x] for every row of `prev` and then make
+// `prev` this frame's coordinates
+struct LcfClearSeg {
+    float *dense;
+    int *prev;
+    const int *cur;
+    const int *k_dev;
+    int cap, c, batch, D, H, W;
+    unsigned blk0; // first workgroup of the record; 0xFFFFFFFF = none
+};
 struct LcfFillPlan {
     LcfFillSeg s[LCF_FILL_MAX_SEGS];
+    LcfClearSeg clr;
     int n;
 };
 struct lcf_ctx {

@@ -95,6 +95,7 @@ extern "C" int lcf_ctx_create(lcf_ctx **out)
     if (!out) return LCF_ERR_ARG;
     lcf_ctx *c = new (std::nothrow) lcf_ctx();
     if (!c) return LCF_ERR_ARG;
+    c->plan.clr.blk0 = 0xFFFFFFFFu; // no clear record
     *out = c;
     return LCF_OK;
 }
@@ -132,14 +133,52 @@ extern "C" int lcf_ctx_set_option(lcf_ctx *ctx, int option, int value)
 // context instead, and the flush runs them as ONE kernel -- the engine re-arms ten hash
 // workspaces and clears the dense output behind a frame's rulebook branch: eleven 4-5 us launches
 // there become one.
+// Rows-only clear of a dense() output (no 18 MB zero fill per frame).
+// `prev` [cap,4] holds the coordinates the PREVIOUS frame's rows were scattered to (-1 = no row);
+// a workgroup zeroes the cells of its four rows in every channel plane, then replaces its rows of
+// `prev` by this frame's coordinates (cur, rows < k; -1 beyond).  Rows belong to one workgroup, so
+// nothing crosses workgroups and no count of the previous frame is needed.
+#define LCF_CLEAR_ROWS_PER_WG 4
+__device__ __forceinline__ void lcf_clear_rows_role(const LcfClearSeg &q, unsigned blk)
+{
+    const int row = (int)blk * LCF_CLEAR_ROWS_PER_WG + (int)(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    int4 pc = make_int4(-1, -1, -1, -1);
+    if (row < q.cap) pc = reinterpret_cast<const int4 *>(q.prev)[row];
+    if (pc.x >= 0 && pc.x < q.batch && pc.y >= 0 && pc.y < q.D && pc.z >= 0 && pc.z < q.H &&
+        pc.w >= 0 && pc.w < q.W) {
+        const size_t svol = (size_t)q.D * q.H * q.W;
+        const size_t sp = ((size_t)pc.y * q.H + pc.z) * q.W + pc.w;
+        float *base = q.dense + (size_t)pc.x * q.c * svol + sp;
+        for (int ch = lane; ch < q.c; ch += 64) base[(size_t)ch * svol] = 0.f;
+    }
+    __syncthreads();
+    if (lane == 0 && row < q.cap) {
+        const int k = lcf_count(q.cap, q.k_dev);
+        int4 nc = make_int4(-1, -1, -1, -1);
+        if (row < k) nc = reinterpret_cast<const int4 *>(q.cur)[row];
+        reinterpret_cast<int4 *>(q.prev)[row] = nc;
+    }
+}
+
+__global__ void __launch_bounds__(256) lcf_clear_rows_kernel(LcfClearSeg q)
+{
+    lcf_clear_rows_role(q, blockIdx.x);
+}
+
 __global__ void __launch_bounds__(256) lcf_fill32_multi_kernel(LcfFillPlan plan)
 {
+    if (blockIdx.x >= plan.clr.blk0) {
+        lcf_clear_rows_role(plan.clr, blockIdx.x - plan.clr.blk0);
+        return;
+    }
     int i = 0;
 #pragma unroll 1
     for (int j = 1; j < plan.n; ++j)
         if (blockIdx.x >= plan.s[j].blk0) i = j;
     const LcfFillSeg sg = plan.s[i];
-    const unsigned nblk = (i + 1 < plan.n ? plan.s[i + 1].blk0 : gridDim.x) - sg.blk0;
+    const unsigned fill_end = plan.clr.blk0 < gridDim.x ? plan.clr.blk0 : gridDim.x;
+    const unsigned nblk = (i + 1 < plan.n ? plan.s[i + 1].blk0 : fill_end) - sg.blk0;
     uint32_t *p = sg.p;
     const size_t n32 = sg.n32;
     size_t head = ((16 - ((uintptr_t)p & 15)) & 15) / 4;
@@ -155,11 +194,23 @@ __global__ void __launch_bounds__(256) lcf_fill32_multi_kernel(LcfFillPlan plan)
     if (t < n32 - tail0) p[tail0 + t] = sg.v;
 }
 
+static unsigned clear_rows_blocks(int cap)
+{
+    return (unsigned)((cap + LCF_CLEAR_ROWS_PER_WG - 1) / LCF_CLEAR_ROWS_PER_WG);
+}
+
 static int fill_plan_launch(lcf_ctx *ctx, hipStream_t st)
 {
-    if (ctx->plan.n == 0) return LCF_OK;
-    lcf_fill32_multi_kernel<<<ctx->fill_blocks, 256, 0, st>>>(ctx->plan);
+    const bool clr = ctx->plan.clr.blk0 != 0xFFFFFFFFu;
+    if (ctx->plan.n == 0 && !clr) return LCF_OK;
+    unsigned blocks = ctx->fill_blocks;
+    if (clr) { // the clear record's workgroups go behind the fills'
+        ctx->plan.clr.blk0 = blocks;
+        blocks += clear_rows_blocks(ctx->plan.clr.cap);
+    }
+    lcf_fill32_multi_kernel<<<blocks, 256, 0, st>>>(ctx->plan);
     ctx->plan.n = 0;
+    ctx->plan.clr.blk0 = 0xFFFFFFFFu;
     ctx->fill_blocks = 0;
     LCF_CHECK_LAUNCH();
     return LCF_OK;
@@ -169,6 +220,7 @@ extern "C" int lcf_ctx_fill_batch_begin(lcf_ctx *ctx)
 {
     if (!ctx) return LCF_ERR_ARG;
     ctx->plan.n = 0;
+    ctx->plan.clr.blk0 = 0xFFFFFFFFu;
     ctx->fill_blocks = 0;
     ctx->batching = 1;
     return LCF_OK;
@@ -199,8 +251,11 @@ int lcf_fill32_ctx(lcf_ctx *ctx, void *p, uint32_t v, size_t bytes, hipStream_t 
     if (!ctx || !ctx->batching) return lcf_fill32(p, v, bytes, st);
     if (bytes == 0) return LCF_OK;
     if ((bytes & 3) || ((uintptr_t)p & 3)) return LCF_ERR_ARG;
-    if (ctx->plan.n == LCF_FILL_MAX_SEGS) { // full: run what is recorded so far
+    if (ctx->plan.n == LCF_FILL_MAX_SEGS) { // full: run the recorded fills (a clear record stays)
+        LcfClearSeg keep = ctx->plan.clr;
+        ctx->plan.clr.blk0 = 0xFFFFFFFFu;
         int rc = fill_plan_launch(ctx, st);
+        ctx->plan.clr = keep;
         if (rc != LCF_OK) return rc;
     }
     const size_t n32 = bytes / 4;
@@ -220,6 +275,35 @@ extern "C" int lcf_fill_u32(void *p, uint32_t value, size_t bytes, void *stream,
 {
     if (!p && bytes) return LCF_ERR_ARG;
     return lcf_fill32_ctx(ctx, p, value, bytes, (hipStream_t)stream);
+}
+
+extern "C" int lcf_dense_clear_rows(float *dense, int *prev_coors, const int *coors, int cap,
+                                    const int *k_dev, int c, int batch, const int shape[3],
+                                    void *stream, lcf_ctx *ctx)
+{
+    if (!dense || !prev_coors || !coors || cap <= 0 || c <= 0 || batch <= 0 || !shape ||
+        shape[0] <= 0 || shape[1] <= 0 || shape[2] <= 0)
+        return LCF_ERR_ARG;
+    LcfClearSeg q;
+    q.dense = dense;
+    q.prev = prev_coors;
+    q.cur = coors;
+    q.k_dev = k_dev;
+    q.cap = cap;
+    q.c = c;
+    q.batch = batch;
+    q.D = shape[0];
+    q.H = shape[1];
+    q.W = shape[2];
+    q.blk0 = 0;
+    if (ctx && ctx->batching) {
+        if (ctx->plan.clr.blk0 != 0xFFFFFFFFu) return LCF_ERR_UNSUPPORTED; // one record per batch
+        ctx->plan.clr = q;
+        return LCF_OK;
+    }
+    lcf_clear_rows_kernel<<<clear_rows_blocks(cap), 256, 0, (hipStream_t)stream>>>(q);
+    LCF_CHECK_LAUNCH();
+    return LCF_OK;
 }
 
 // ---------------------------------------------------------------- frame hand-over

@@ -47,7 +47,12 @@ vox_insert_kernel(const float *__restrict__ pts, int n_begin, int n_cap,
     // the start of a session
     const int gid = blockIdx.x * VOX_BLOCK + threadIdx.x;
     if (gid < scan_nblk) scan_state[gid] = 0;
-    if (gid == 0 && n_begin == 0) ctrl[0] = 0x7FFFFFFF;
+    if (gid == 0) {
+        // ctrl[0] = i*, ctrl[1] = first points so far, ctrl[2] = that count before this call,
+        // ctrl[3] = blocks of vox_scan_kernel that gave up waiting and counted for themselves
+        if (n_begin == 0) ctrl[0] = 0x7FFFFFFF, ctrl[3] = 0;
+        ctrl[2] = n_begin == 0 ? 0 : ctrl[1];
+    }
     int i = n_begin + gid;
     if (i >= n) return;
     int c[3];
@@ -149,19 +154,23 @@ vox_assign_kernel(const int *__restrict__ cellslot, const int *__restrict__ list
 }
 
 // vox_count_kernel + vox_assign_kernel as ONE launch (decoupled look-back over the per-block
-// counts: a block publishes its count, adds up what its predecessors published -- blocks are
-// dispatched in index order and publish before they wait -- and hands out the ids; the same ids
-// as the two-launch form).  state[b] = status << 30 | value: 0 nothing yet (cleared by
-// vox_insert_kernel, one launch earlier), 1 the block's own count, 2 the count up to and
-// including b (block 0: on top of the first points of the earlier calls of the session).  A wait
-// that does not end within VOX_SPIN_LIMIT polls gives up (the ids are then wrong, the call does
-// not hang).  The voxelizer is the head of a frame's critical path: one launch less is 5 us.
-#define VOX_SPIN_LIMIT (1 << 22)
+// counts: a block publishes its count, adds up what its predecessors published and hands out the
+// ids; the same ids as the two-launch form).  state[b] = status << 30 | value: 0 nothing yet
+// (cleared by vox_insert_kernel, one launch earlier), 1 the block's own count, 2 the count up to
+// and including b (block 0: on top of the first points of the earlier calls of the session).
+// Blocks are normally dispatched in index order and publish before they wait, so a wait is short;
+// HIP does not promise that order, so a wait that does not end within `spin_limit` polls stops
+// waiting and the block COUNTS THE FIRST POINTS IN FRONT OF IT ITSELF (the inserts finished a
+// launch ago: flags of other blocks' points are plain reads).  The ids are therefore right
+// whatever the dispatch order, the call never hangs, and ctrl[3] counts the blocks that took
+// the slow way (lcf_voxelize_scan_fallbacks; FrameEngine.check() reports it).  The voxelizer is
+// the head of a frame's critical path: one launch less is 5 us.
+#define VOX_SPIN_LIMIT (1 << 16)
 __global__ void __launch_bounds__(VOX_BLOCK)
 vox_scan_kernel(const int *__restrict__ cellslot, const int *__restrict__ lists, int max_pts,
                 int n_begin, int n_cap, const int *__restrict__ n_dev, int *__restrict__ bsums,
                 int max_vox, int *__restrict__ pvid, int *__restrict__ ctrl,
-                int *__restrict__ voxel_num, int init_istar)
+                int *__restrict__ voxel_num, int have_insert, int spin_limit)
 {
     __shared__ int lds[8];
     const int n = lcf_count(n_cap, n_dev);
@@ -181,18 +190,23 @@ vox_scan_kernel(const int *__restrict__ cellslot, const int *__restrict__ lists,
         const int lane = threadIdx.x;
         int sum = 0;
         if (blk == 0) {
-            // ctrl[0] = i*, ctrl[1] = first points so far, ctrl[2] = that count before this call
             if (lane == 0) {
-                sum = n_begin == 0 ? 0 : ctrl[1];
-                ctrl[2] = sum;
-                if (init_istar) ctrl[0] = 0x7FFFFFFF; // (no insert launch ran: nothing races)
+                // the first points of the session's earlier calls: ctrl[2], written by the insert
+                // launch; with no insert launch (nothing new) this is the grid's only block
+                if (have_insert) {
+                    sum = ctrl[2];
+                } else {
+                    sum = n_begin == 0 ? 0 : ctrl[1];
+                    ctrl[2] = sum;
+                    if (n_begin == 0) ctrl[0] = 0x7FFFFFFF, ctrl[3] = 0;
+                }
                 atomicExch(&state[0], (2u << 30) | (unsigned)(sum + total));
             }
             sum = __shfl(sum, 0, 64);
         } else {
             if (lane == 0) atomicExch(&state[blk], (1u << 30) | (unsigned)total);
             int pos = blk - 1, polls = 0;
-            bool done = false;
+            bool done = false, gave_up = false;
             while (!done) {
                 const int idx = pos - lane;
                 unsigned v = 2u << 30;
@@ -200,7 +214,7 @@ vox_scan_kernel(const int *__restrict__ cellslot, const int *__restrict__ lists,
                     v = __hip_atomic_load(&state[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const unsigned stt = v >> 30;
                 if (__ballot(stt == 0u) != 0ull) {
-                    if (++polls > VOX_SPIN_LIMIT) done = true;
+                    if (++polls > spin_limit) done = gave_up = true;
                     __builtin_amdgcn_s_sleep(1);
                     continue;
                 }
@@ -214,6 +228,18 @@ vox_scan_kernel(const int *__restrict__ cellslot, const int *__restrict__ lists,
                     done = true;
                 else
                     pos -= 64;
+            }
+            if (gave_up) {
+                // a predecessor has not published: count every first point in front of this
+                // block directly, on top of the earlier calls' count
+                const int end = n_begin + blk * VOX_BLOCK * VOX_ITEMS;
+                int c = 0;
+                for (int i = n_begin + lane; i < end; i += 64)
+                    c += vox_is_first(cellslot, lists, max_pts, i, n);
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d, 64);
+                sum = c + ctrl[2];
+                if (lane == 0) atomicAdd(&ctrl[3], 1);
             }
             if (lane == 0) atomicExch(&state[blk], (2u << 30) | (unsigned)(sum + total));
         }
@@ -392,6 +418,10 @@ static int vox_run(const float *points, int n, const int *n_dev, int f, const fl
     if (nblk < 1) nblk = 1;
     // LCF_VOX_TWO_PASS (environment, A/B and fallback): count and assign as two launches
     static const bool two_pass = getenv("LCF_VOX_TWO_PASS") != nullptr;
+    // LCF_VOX_SPIN_LIMIT (environment, tests): polls a block of the one-launch scan waits for a
+    // predecessor before it counts for itself; 0 forces that path wherever a wait would start
+    static const int spin_limit =
+        getenv("LCF_VOX_SPIN_LIMIT") ? atoi(getenv("LCF_VOX_SPIN_LIMIT")) : VOX_SPIN_LIMIT;
     if (n_new > 0) {
         vox_insert_kernel<<<(n_new + VOX_BLOCK - 1) / VOX_BLOCK, VOX_BLOCK, 0, st>>>(
             points, n_begin, n, n_dev, f, p, max_pts, w.keys, w.hc - 1, w.lists, w.cellslot,
@@ -408,7 +438,7 @@ static int vox_run(const float *points, int n, const int *n_dev, int f, const fl
     } else {
         vox_scan_kernel<<<nblk, VOX_BLOCK, 0, st>>>(w.cellslot, w.lists, max_pts, n_begin, n, n_dev,
                                                     w.bsums, max_vox, w.pvid, w.ctrl, voxel_num,
-                                                    n_new > 0 ? 0 : (n_begin == 0 ? 1 : 0));
+                                                    n_new > 0 ? 1 : 0, spin_limit);
     }
     LCF_CHECK_LAUNCH();
     int m = n_begin == 0 && max_vox > n_new ? max_vox : n_new;
@@ -445,7 +475,20 @@ extern "C" int lcf_voxelize_append(const float *points, int n_capacity, int n_be
     const bool ws_clean = ctx && ctx->o.ws_clean;
     return vox_run(points, n_end, nullptr, f, vs, range, max_pts, max_vox, cap_mode, batch_idx,
                    coor_stride, voxels, coors, num_pts, voxel_num, ws, ws_bytes,
-                   n_begin == 0 && !ws_clean, (hipStream_t)stream, n_begin, n_capacity, ctx);
+                   n_begin == 0 && !ws_clean, (hipStream_t)stream, n_begin, n_capacity);
+}
+
+// Device address of the workspace's counter of vox_scan_kernel blocks that stopped waiting for a
+// predecessor and counted for themselves since the session began (results are right either way;
+// a non-zero count says the one-launch scan ran slowly, e.g. under heavy concurrent streams).
+extern "C" int lcf_voxelize_scan_fallbacks(void *ws, size_t ws_bytes, int n, int max_pts,
+                                           const int **counter_dev)
+{
+    if (!ws || n < 0 || max_pts <= 0 || !counter_dev) return LCF_ERR_ARG;
+    VoxWs w = vox_carve(ws, n, max_pts);
+    if (ws_bytes < w.bytes) return LCF_ERR_WORKSPACE;
+    *counter_dev = w.ctrl + 3;
+    return LCF_OK;
 }
 
 // ---------------------------------------------------------------- the entry point that allocates

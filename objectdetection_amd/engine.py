@@ -46,7 +46,7 @@ class _Layer:
 
 class FrameEngine:
     def __init__(self, model, max_points=None, calib=None, margin=2.0, use_graph=True,
-                 two_streams=True, conv_math="f32", dense_out=None):
+                 two_streams=True, conv_math="f32", dense_out=None, dense_clear="full"):
         """model: objectdetection_amd.frontend.SparseFrontEnd in eval mode on a GPU.
         max_points: capacity of the point buffer (default: 2 x the largest calibration cloud).
         calib: list of [N,F] float32 cuda clouds used to size the strided levels.
@@ -79,6 +79,14 @@ class FrameEngine:
         self.two_streams = bool(two_streams)
         # dense() fused into the last conv's epilogue (lcf_indice_conv_fwd_dense)
         self.fuse_dense = os.environ.get("LCF_ENGINE_FUSE_DENSE", "1") != "0"
+        # dense_clear="rows": the dense output is cleared by ROWS -- only the cells the previous
+        # frame wrote (lcf_dense_clear_rows; SURVEY.md 8f-1: ~2 MB of stores instead of the whole
+        # 18 MB buffer per frame).  Measured in round 3 (A/B on one box, 300 frames each, twice):
+        # 1642 / 1641 frames/s with the whole-buffer fill, 1627 / 1626 with the row clear -- the
+        # rows are ~8k x 64 isolated 4-byte stores, one cache line each, and cost the memory system
+        # more than 18 MB of streaming 16-byte stores on the side stream do.  So the fill stays the
+        # default and the row clear is an option (LCF_ENGINE_DENSE_CLEAR=rows|full overrides).
+        self.clear_rows = os.environ.get("LCF_ENGINE_DENSE_CLEAR", dense_clear) == "rows"
         self.side = torch.cuda.Stream(device=self.dev) if self.two_streams else None
         # capacities = margin x the calibrated counts.  The hash tables of the rulebook chain are
         # sized from them, and emptier tables probe less: 2.0 is the fastest in the frame (1.1 /
@@ -305,6 +313,14 @@ class FrameEngine:
                                  f"tensor on {dev}")
             self.dense = d
         self.out = self.dense.view(1, C * D, H, W)
+        # rows-only clearing: the coordinates the rows of the dense output come from (the last
+        # strided level's, or the voxels') and where the previous frame's rows went (-1 = none)
+        self.final_coors, self.final_k, self.final_cap = self.coors, self.vnum, MV
+        for l in self.layers:
+            if not l.subm:
+                self.final_coors, self.final_k, self.final_cap = l.out_coors, l.k_out, l.k_out_cap
+        self.prev_coors = torch.full((self.final_cap, 4), -1, dtype=i32, device=dev)
+        self.dense.zero_()
         self.graph = None
         self._reset_workspaces(torch.cuda.current_stream(dev).cuda_stream)
         self._ws_dirty = False
@@ -333,6 +349,8 @@ class FrameEngine:
             # half-built frame, and this frame's calls skip their own resets
             self.ctx.fill_batch_flush(torch.cuda.current_stream(self.dev).cuda_stream)
             self._reset_workspaces(torch.cuda.current_stream(self.dev).cuda_stream)
+            self.dense.zero_()  # (and which of its cells hold a frame is unknown)
+            self.prev_coors.fill_(-1)
         self._ws_dirty = True
         self._enqueue_clean()
         self._ws_dirty = False
@@ -383,7 +401,13 @@ class FrameEngine:
                 if batch:
                     self.ctx.fill_batch_begin()
                 try:
-                    check(L.lcf_fill_u32(P(self.dense), 0, self.dense.numel() * 4, sst, cx))
+                    if self.clear_rows:
+                        check(L.lcf_dense_clear_rows(
+                            P(self.dense), P(self.prev_coors), P(self.final_coors),
+                            self.final_cap, P(self.final_k), self.dense.shape[1], 1,
+                            i3(self.out_shape), sst, cx))
+                    else:
+                        check(L.lcf_fill_u32(P(self.dense), 0, self.dense.numel() * 4, sst, cx))
                     if self.two_streams and not batch:
                         side_state["e_dense"] = torch.cuda.Event()
                         side_state["e_dense"].record(side)
@@ -597,6 +621,17 @@ class FrameEngine:
                 "FrameEngine: a strided level exceeded its capacity "
                 f"{self.level_caps}; re-create the engine with a larger margin or calibrate on "
                 "denser frames (or call forward(..., sync=True), which re-plans by itself)")
+
+    def scan_fallbacks(self):
+        """Blocks of the voxelizer's one-launch scan that stopped waiting for a predecessor and
+        counted for themselves in the last frame (include/lcf.h: lcf_voxelize_scan_fallbacks;
+        the frame is right either way, only slower).  Synchronises."""
+        import ctypes
+        ptr = ctypes.c_void_p()
+        check(self.L.lcf_voxelize_scan_fallbacks(self.vox_ws.data_ptr(), self.vox_ws.numel(),
+                                                 self.max_points, self.T, ctypes.byref(ptr)))
+        off = ptr.value - self.vox_ws.data_ptr()
+        return int(self.vox_ws[off:off + 4].view(torch.int32).item())
 
     def counts(self):
         """[voxels, active sites after each strided conv] of the last frame (synchronises)."""

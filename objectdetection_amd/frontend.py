@@ -61,12 +61,13 @@ class SparseFrontEnd(nn.Module):
         return torch.cat(vs), torch.cat(ns), torch.cat(cs)
 
     def engine(self, calib=None, max_points=None, margin=2.0, use_graph=True, two_streams=True,
-               conv_math="f32"):
+               conv_math="f32", **engine_kw):
         """Batch-1 inference engine: the whole frame as one hipGraph replay without host
         synchronisation (objectdetection_amd/engine.py).  ``calib``: sample clouds that size it."""
         from .engine import FrameEngine
         return FrameEngine(self, max_points=max_points, calib=calib, margin=margin,
-                           use_graph=use_graph, two_streams=two_streams, conv_math=conv_math)
+                           use_graph=use_graph, two_streams=two_streams, conv_math=conv_math,
+                           **engine_kw)
 
     def forward(self, clouds):
         voxels, num_points, coors = self.voxelize(clouds)

@@ -246,6 +246,76 @@ def test_batched_fills_run_as_one_launch_with_the_same_result(cuda):
     assert int(bufs[0][0]) == 1
 
 
+def test_dense_clear_rows_through_the_c_abi(cuda):
+    """lcf_dense_clear_rows: the cells the previous frame's rows were scattered
+    to are zeroed, `prev_coors` becomes this frame's coordinates (-1 beyond the count); alone
+    and as the one clear record of a fill batch (behind recorded fills), ragged sizes."""
+    L = _lib.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    C, D, H, W, cap = 64, 2, 20, 17, 301
+    shape = _lib.i3((D, H, W))
+    g = torch.Generator().manual_seed(3)
+
+    def frame(k):
+        cells = torch.randperm(D * H * W, generator=g)[:k]
+        co = torch.zeros((cap, 4), dtype=torch.int32)
+        co[:k, 1], co[:k, 2], co[:k, 3] = cells // (H * W), cells // W % H, cells % W
+        co[k:] = 12345  # stale rows beyond the count: never read as coordinates
+        return co.to(cuda)
+
+    def scatter(dense, co, k):
+        idx = co[:k].long()
+        dense[0, :, idx[:, 1], idx[:, 2], idx[:, 3]] = torch.rand((C, k), device=cuda) + 1.0
+
+    for batched in (False, True):
+        dense = torch.zeros((1, C, D, H, W), device=cuda)
+        prev = torch.full((cap, 4), -1, dtype=torch.int32, device=cuda)
+        k_dev = torch.zeros(1, dtype=torch.int32, device=cuda)
+        ctx = _lib.Context()
+        side = torch.full((1000,), 7, dtype=torch.int32, device=cuda)
+        for k in (200, 301, 0, 5, 150):
+            co = frame(k)
+            k_dev.fill_(k)
+            if batched:
+                ctx.fill_batch_begin()
+                assert L.lcf_fill_u32(side.data_ptr(), k, 4000, st, ctx.handle) == 0
+            assert L.lcf_dense_clear_rows(dense.data_ptr(), prev.data_ptr(), co.data_ptr(), cap,
+                                          k_dev.data_ptr(), C, 1, shape, st,
+                                          ctx.handle if batched else None) == 0
+            if batched:
+                # a second record in one batch is refused
+                assert L.lcf_dense_clear_rows(dense.data_ptr(), prev.data_ptr(), co.data_ptr(),
+                                              cap, k_dev.data_ptr(), C, 1, shape, st,
+                                              ctx.handle) == -3
+                ctx.fill_batch_flush(st)
+                assert int((side != k).sum()) == 0
+            assert float(dense.abs().sum()) == 0.0  # everything the last frame wrote is gone
+            assert torch.equal(prev[:k], co[:k]) and int((prev[k:] != -1).sum()) == 0
+            scatter(dense, co, k)
+    assert L.lcf_dense_clear_rows(None, prev.data_ptr(), co.data_ptr(), cap, None, C, 1, shape,
+                                  st, None) == -1
+
+
+def test_engine_clears_only_the_rows_of_the_previous_frame(cuda):
+    """The engine's dense output equals the whole-buffer-fill engine's bit for bit over frames of
+    different sizes (a small frame after a large one leaves no stale cell), through the graph."""
+    model = randomize_(SparseFrontEnd("M1").eval(), 0).to(cuda)
+    calib = _clouds(cuda, [0, 1], 20000)
+    with torch.no_grad(), one_wave_set():
+        eng = model.engine(calib=calib, dense_clear="rows")
+        assert eng.clear_rows
+        full = model.engine(calib=calib)
+        assert not full.clear_rows
+        for seed, n in [(0, 20000), (7, 3000), (1, 20000), (9, 100), (5, 12000), (5, 12000)]:
+            c = torch.from_numpy(synth.vkitti_frame(seed, n)).to(cuda)
+            a, b = eng.forward(c).clone(), full.forward(c).clone()
+            eng.check()
+            assert torch.equal(a, b), (seed, n)
+        empty = torch.zeros((0, 4), device=cuda)
+        assert float(eng.forward(empty).abs().sum()) == 0.0
+        assert eng.scan_fallbacks() == 0
+
+
 def test_two_engines_enqueue_from_two_threads(cuda):
     """Re-entrancy (SURVEY.md section 8b "Threading"): each engine owns its lcf_ctx, so two engines
     -- eager enqueue, i.e. ~60 option-dependent C calls per frame each -- driven from two threads
