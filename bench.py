@@ -303,12 +303,10 @@ def main(argv=None):
     args = ap.parse_args(argv)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        # not under a launcher: become the launcher (no GPU call has happened in this process)
-        if os.environ.get("LCF_REHEARSE") != "1" and torch.cuda.device_count() < args.gpus:
-            print(f"bench.py: --gpus {args.gpus} but only {torch.cuda.device_count()} GPU(s) are "
-                  "visible (LCF_REHEARSE=1 rehearses the control flow on one GPU over gloo)",
-                  file=sys.stderr)
-            return 2
+        # not under a launcher: become the launcher.  This process stays GPU-free -- it makes no
+        # HIP call at all, not even a device count (a launcher that has initialised the GPU must
+        # not start other GPU programs on this pool); a rank whose LOCAL_RANK has no device
+        # refuses below with exit code 2
         return launch_ranks(args.gpus, argv)
 
     rank = int(os.environ.get("RANK", "0"))
@@ -321,6 +319,11 @@ def main(argv=None):
         import faulthandler
         faulthandler.dump_traceback_later(int(os.environ.get("LCF_REHEARSE_DUMP", "100")),
                                           exit=True)
+    if not rehearse and local_rank >= torch.cuda.device_count():
+        print(f"bench.py: rank {rank} (LOCAL_RANK {local_rank}) has no GPU: --gpus {args.gpus} but "
+              f"only {torch.cuda.device_count()} GPU(s) are visible (LCF_REHEARSE=1 rehearses the "
+              "control flow on one GPU over gloo)", file=sys.stderr)
+        return 2
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
     if world > 1:

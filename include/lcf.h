@@ -505,6 +505,25 @@ int lcf_bn_relu_fwd(const float *x, int k, int c, const float *gamma, const floa
 int lcf_bn_relu_bwd(const float *x, const float *y, const float *dy, int k, int c,
                     const float *gamma, const float *stats, int relu, float *dx, float *dgamma,
                     float *dbeta, void *ws, size_t ws_bytes, void *stream);
+/* The same pair with rows stored as fp32 or bf16 (*_bf16 = 1: that tensor's rows are bf16, c a
+ * multiple of 8) and the module's running statistics updated by the forward itself.  bf16 rows
+ * are for the tensors a sparse conv GATHERS: this pair's output y (the next conv's input) and
+ * the gradient dx it hands back (the dgrad / wgrad operand of the conv in front), so that the
+ * gathers of the training step move 128-byte rows (BASELINE.json configs[2]: bf16 MFMA
+ * indice_conv); conv outputs x stay fp32 and every statistic, sum and product here is fp32 /
+ * double.  Values are rounded to nearest even when stored.
+ * running_mean / running_var [c] (both or neither) and num_batches_tracked [1] int64 (or NULL):
+ * mean <- (1-m) mean + m batch_mean, var <- (1-m) var + m unbiased batch var, batches += 1, as
+ * nn.BatchNorm1d does after its forward (torch/nn/modules/batchnorm.py; the reference's
+ * momentum 0.01, second/pytorch/models/middle.py:124). */
+int lcf_bn_relu_fwd_ex(const void *x, int x_bf16, int k, int c, const float *gamma,
+                       const float *beta, float eps, int relu, void *y, int y_bf16, float *stats,
+                       float *running_mean, float *running_var, long long *num_batches_tracked,
+                       float momentum, void *ws, size_t ws_bytes, void *stream);
+int lcf_bn_relu_bwd_ex(const void *x, int x_bf16, const void *y, int y_bf16, const void *dy,
+                       int dy_bf16, int k, int c, const float *gamma, const float *stats, int relu,
+                       void *dx, int dx_bf16, float *dgamma, float *dbeta, void *ws,
+                       size_t ws_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Rotated / axis-aligned IoU and non-maximum suppression (the predict-time

@@ -164,6 +164,13 @@ SYMBOLS = {
     "lcf_bn_workspace_bytes": (c_size_t, [c_int, c_int]),
     "lcf_bn_relu_fwd": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, ctypes.c_float, c_int,
                                 c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "lcf_bn_relu_fwd_ex": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,
+                                   ctypes.c_float, c_int, c_void_p, c_int, c_void_p, c_void_p,
+                                   c_void_p, c_void_p, ctypes.c_float, c_void_p, c_size_t,
+                                   c_void_p]),
+    "lcf_bn_relu_bwd_ex": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int,
+                                   c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p,
+                                   c_void_p, c_void_p, c_size_t, c_void_p]),
     "lcf_bn_relu_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p,
                                 c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
                                 c_void_p]),

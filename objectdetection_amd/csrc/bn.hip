@@ -31,6 +31,41 @@ __device__ __forceinline__ BnMap bn_map(int c)
     return m;
 }
 
+// Rows are fp32 or bf16 (round 3: the activations a sparse conv GATHERS -- the output y of this
+// pair and the gradient dx it hands back -- can be stored as bf16 so that the gathers move
+// 128-byte rows; statistics, sums and the arithmetic stay fp32 / double).  T = float | __bf16.
+template <typename T>
+__device__ __forceinline__ float4 bn_ld4(const T *row, int c4)
+{
+    if constexpr (sizeof(T) == 4) {
+        return reinterpret_cast<const float4 *>(row)[c4];
+    } else {
+        const uint2 u = reinterpret_cast<const uint2 *>(row)[c4];
+        return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xFFFF0000u),
+                           __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xFFFF0000u));
+    }
+}
+
+__device__ __forceinline__ unsigned bn_bf16_rne(float f)
+{
+    unsigned u = __float_as_uint(f);
+    if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (u >> 16) | 0x40u; // NaN stays NaN
+    return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;                  // round to nearest even
+}
+
+template <typename T>
+__device__ __forceinline__ void bn_st4(T *row, int c4, float4 v)
+{
+    if constexpr (sizeof(T) == 4) {
+        reinterpret_cast<float4 *>(row)[c4] = v;
+    } else {
+        uint2 u;
+        u.x = bn_bf16_rne(v.x) | (bn_bf16_rne(v.y) << 16);
+        u.y = bn_bf16_rne(v.z) | (bn_bf16_rne(v.w) << 16);
+        reinterpret_cast<uint2 *>(row)[c4] = u;
+    }
+}
+
 // block-level sum of two float4 per thread over the row lanes -> part[0:c] and part[c:2c]
 __device__ __forceinline__ void bn_block_reduce(const BnMap &m, int c, float4 a, float4 b,
                                                 float *lds, float *part)
@@ -51,8 +86,9 @@ __device__ __forceinline__ void bn_block_reduce(const BnMap &m, int c, float4 a,
 }
 
 // ---- forward 1: partial sums of x and x^2
+template <typename TX>
 __global__ void __launch_bounds__(BN_BLOCK)
-bn_stats_kernel(const float *__restrict__ x, int k, int c, int rows_per_block,
+bn_stats_kernel(const TX *__restrict__ x, int k, int c, int rows_per_block,
                 float *__restrict__ parts)
 {
     __shared__ __align__(16) float lds[BN_BLOCK * 8];
@@ -62,7 +98,7 @@ bn_stats_kernel(const float *__restrict__ x, int k, int c, int rows_per_block,
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f), q = s;
     if (m.rl < m.RL) {
         for (int r = r0 + m.rl; r < r1; r += m.RL) {
-            const float4 v = reinterpret_cast<const float4 *>(x + (size_t)r * c)[m.c4];
+            const float4 v = bn_ld4(x + (size_t)r * c, m.c4);
             s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
             q.x += v.x * v.x; q.y += v.y * v.y; q.z += v.z * v.z; q.w += v.w * v.w;
         }
@@ -83,11 +119,20 @@ bn_finalize_kernel(const float *__restrict__ parts, int nparts, int c2, double *
 }
 
 // ---- forward 2: mean / biased var from the partials, y = relu(x * scale + shift)
+// running statistics of nn.BatchNorm1d, updated by block 0 when the caller passes them (what the
+// module does after its forward: unbiased variance, momentum; five tiny launches otherwise)
+struct BnRunning {
+    float *mean, *var;
+    long long *batches;
+    float momentum;
+};
+
+template <typename TX, typename TY>
 __global__ void __launch_bounds__(BN_BLOCK)
-bn_apply_relu_kernel(const float *__restrict__ x, int k, int c, int rows_per_block,
+bn_apply_relu_kernel(const TX *__restrict__ x, int k, int c, int rows_per_block,
                      const double *__restrict__ sums,
                      const float *__restrict__ gamma, const float *__restrict__ beta, float eps,
-                     int relu, float *__restrict__ y, float *__restrict__ stats)
+                     int relu, TY *__restrict__ y, float *__restrict__ stats, BnRunning run)
 {
     __shared__ __align__(16) float sc[BN_MAX_C], sh[BN_MAX_C];
     for (int e = threadIdx.x; e < c; e += BN_BLOCK) {
@@ -102,6 +147,13 @@ bn_apply_relu_kernel(const float *__restrict__ x, int k, int c, int rows_per_blo
             stats[e] = (float)mean;
             stats[c + e] = (float)var;
             stats[2 * c + e] = inv;
+            if (run.mean) {
+                const float mo = run.momentum;
+                run.mean[e] = (1.f - mo) * run.mean[e] + mo * (float)mean;
+                run.var[e] = (1.f - mo) * run.var[e] +
+                             mo * (float)(var * ((double)k / (double)(k > 1 ? k - 1 : 1)));
+                if (e == 0 && run.batches) run.batches[0] += 1;
+            }
         }
     }
     __syncthreads();
@@ -112,21 +164,22 @@ bn_apply_relu_kernel(const float *__restrict__ x, int k, int c, int rows_per_blo
     const int r0 = blockIdx.x * rows_per_block;
     const int r1 = min(k, r0 + rows_per_block);
     for (int r = r0 + m.rl; r < r1; r += m.RL) {
-        float4 v = reinterpret_cast<const float4 *>(x + (size_t)r * c)[m.c4];
+        float4 v = bn_ld4(x + (size_t)r * c, m.c4);
         v.x = v.x * a.x + b.x; v.y = v.y * a.y + b.y;
         v.z = v.z * a.z + b.z; v.w = v.w * a.w + b.w;
         if (relu) {
             v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f);
             v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
         }
-        reinterpret_cast<float4 *>(y + (size_t)r * c)[m.c4] = v;
+        bn_st4(y + (size_t)r * c, m.c4, v);
     }
 }
 
 // ---- backward 1: partial sums of g = dy * (y > 0) and of g * xhat, xhat = (x - mean) * inv
+template <typename TX, typename TY, typename TG>
 __global__ void __launch_bounds__(BN_BLOCK)
-bn_bwd_reduce_kernel(const float *__restrict__ x, const float *__restrict__ y,
-                     const float *__restrict__ dy, int k, int c, int rows_per_block,
+bn_bwd_reduce_kernel(const TX *__restrict__ x, const TY *__restrict__ y,
+                     const TG *__restrict__ dy, int k, int c, int rows_per_block,
                      const float *__restrict__ stats, int relu, float *__restrict__ parts)
 {
     __shared__ __align__(16) float lds[BN_BLOCK * 8];
@@ -138,10 +191,10 @@ bn_bwd_reduce_kernel(const float *__restrict__ x, const float *__restrict__ y,
         const float4 mean = reinterpret_cast<const float4 *>(stats)[m.c4];
         const float4 inv = reinterpret_cast<const float4 *>(stats + 2 * c)[m.c4];
         for (int r = r0 + m.rl; r < r1; r += m.RL) {
-            const float4 xv = reinterpret_cast<const float4 *>(x + (size_t)r * c)[m.c4];
-            float4 g = reinterpret_cast<const float4 *>(dy + (size_t)r * c)[m.c4];
+            const float4 xv = bn_ld4(x + (size_t)r * c, m.c4);
+            float4 g = bn_ld4(dy + (size_t)r * c, m.c4);
             if (relu) {
-                const float4 yv = reinterpret_cast<const float4 *>(y + (size_t)r * c)[m.c4];
+                const float4 yv = bn_ld4(y + (size_t)r * c, m.c4);
                 g.x = yv.x > 0.f ? g.x : 0.f; g.y = yv.y > 0.f ? g.y : 0.f;
                 g.z = yv.z > 0.f ? g.z : 0.f; g.w = yv.w > 0.f ? g.w : 0.f;
             }
@@ -154,11 +207,12 @@ bn_bwd_reduce_kernel(const float *__restrict__ x, const float *__restrict__ y,
 }
 
 // ---- backward 2: dx = gamma * inv * (g - mean(g) - xhat * mean(g * xhat)); dgamma, dbeta
+template <typename TX, typename TY, typename TG, typename TD>
 __global__ void __launch_bounds__(BN_BLOCK)
-bn_bwd_apply_kernel(const float *__restrict__ x, const float *__restrict__ y,
-                    const float *__restrict__ dy, int k, int c, int rows_per_block,
+bn_bwd_apply_kernel(const TX *__restrict__ x, const TY *__restrict__ y,
+                    const TG *__restrict__ dy, int k, int c, int rows_per_block,
                     const float *__restrict__ stats, const double *__restrict__ sums,
-                    const float *__restrict__ gamma, int relu, float *__restrict__ dx,
+                    const float *__restrict__ gamma, int relu, TD *__restrict__ dx,
                     float *__restrict__ dgamma, float *__restrict__ dbeta)
 {
     __shared__ __align__(16) float mg[BN_MAX_C], mgx[BN_MAX_C], gi[BN_MAX_C];
@@ -184,10 +238,10 @@ bn_bwd_apply_kernel(const float *__restrict__ x, const float *__restrict__ y,
     const int r0 = blockIdx.x * rows_per_block;
     const int r1 = min(k, r0 + rows_per_block);
     for (int r = r0 + m.rl; r < r1; r += m.RL) {
-        const float4 xv = reinterpret_cast<const float4 *>(x + (size_t)r * c)[m.c4];
-        float4 g = reinterpret_cast<const float4 *>(dy + (size_t)r * c)[m.c4];
+        const float4 xv = bn_ld4(x + (size_t)r * c, m.c4);
+        float4 g = bn_ld4(dy + (size_t)r * c, m.c4);
         if (relu) {
-            const float4 yv = reinterpret_cast<const float4 *>(y + (size_t)r * c)[m.c4];
+            const float4 yv = bn_ld4(y + (size_t)r * c, m.c4);
             g.x = yv.x > 0.f ? g.x : 0.f; g.y = yv.y > 0.f ? g.y : 0.f;
             g.z = yv.z > 0.f ? g.z : 0.f; g.w = yv.w > 0.f ? g.w : 0.f;
         }
@@ -196,7 +250,7 @@ bn_bwd_apply_kernel(const float *__restrict__ x, const float *__restrict__ y,
         o.y = w.y * (g.y - a.y - (xv.y - mean.y) * inv.y * b.y);
         o.z = w.z * (g.z - a.z - (xv.z - mean.z) * inv.z * b.z);
         o.w = w.w * (g.w - a.w - (xv.w - mean.w) * inv.w * b.w);
-        reinterpret_cast<float4 *>(dx + (size_t)r * c)[m.c4] = o;
+        bn_st4(dx + (size_t)r * c, m.c4, o);
     }
 }
 
@@ -225,34 +279,88 @@ extern "C" size_t lcf_bn_workspace_bytes(int k, int c)
     return (size_t)BN_MAX_PARTS * 2 * c * sizeof(float) + (size_t)2 * c * sizeof(double);
 }
 
-extern "C" int lcf_bn_relu_fwd(const float *x, int k, int c, const float *gamma,
-                               const float *beta, float eps, int relu, float *y, float *stats,
-                               void *ws, size_t ws_bytes, void *stream)
+// dtype codes of the _ex entry points: 0 = fp32 rows, 1 = bf16 rows
+static int bn_fwd_run(const void *x, int x_bf16, int k, int c, const float *gamma,
+                      const float *beta, float eps, int relu, void *y, int y_bf16, float *stats,
+                      BnRunning run, void *ws, size_t ws_bytes, void *stream)
 {
     int rc = bn_check(k, c);
     if (rc) return rc;
     if (!x || !y || !stats || !ws) return LCF_ERR_ARG;
     if (((uintptr_t)x & 15) || ((uintptr_t)y & 15) || ((uintptr_t)stats & 15)) return LCF_ERR_ARG;
+    if (x_bf16 < 0 || x_bf16 > 1 || y_bf16 < 0 || y_bf16 > 1) return LCF_ERR_ARG;
+    if ((x_bf16 || y_bf16) && (c & 7)) return LCF_ERR_UNSUPPORTED; // 16-byte aligned bf16 rows
     if (ws_bytes < lcf_bn_workspace_bytes(k, c)) return LCF_ERR_WORKSPACE;
     int rpb, np;
     bn_partition(k, &rpb, &np);
     hipStream_t st = (hipStream_t)stream;
     float *parts = (float *)ws;
     double *sums = (double *)((char *)ws + (size_t)BN_MAX_PARTS * 2 * c * sizeof(float));
-    bn_stats_kernel<<<np, BN_BLOCK, 0, st>>>(x, k, c, rpb, parts);
+    if (x_bf16)
+        bn_stats_kernel<__bf16><<<np, BN_BLOCK, 0, st>>>((const __bf16 *)x, k, c, rpb, parts);
+    else
+        bn_stats_kernel<float><<<np, BN_BLOCK, 0, st>>>((const float *)x, k, c, rpb, parts);
     LCF_CHECK_LAUNCH();
     bn_finalize_kernel<<<2 * c, 64, 0, st>>>(parts, np, 2 * c, sums);
     LCF_CHECK_LAUNCH();
-    bn_apply_relu_kernel<<<np, BN_BLOCK, 0, st>>>(x, k, c, rpb, sums, gamma, beta, eps, relu, y,
-                                                 stats);
+#define BN_APPLY(TX, TY)                                                                       \
+    bn_apply_relu_kernel<TX, TY><<<np, BN_BLOCK, 0, st>>>((const TX *)x, k, c, rpb, sums, gamma, \
+                                                          beta, eps, relu, (TY *)y, stats, run)
+    if (x_bf16 && y_bf16) BN_APPLY(__bf16, __bf16);
+    else if (x_bf16) BN_APPLY(__bf16, float);
+    else if (y_bf16) BN_APPLY(float, __bf16);
+    else BN_APPLY(float, float);
+#undef BN_APPLY
     LCF_CHECK_LAUNCH();
     return LCF_OK;
 }
 
-extern "C" int lcf_bn_relu_bwd(const float *x, const float *y, const float *dy, int k, int c,
-                               const float *gamma, const float *stats, int relu, float *dx,
-                               float *dgamma, float *dbeta, void *ws, size_t ws_bytes,
-                               void *stream)
+extern "C" int lcf_bn_relu_fwd(const float *x, int k, int c, const float *gamma,
+                               const float *beta, float eps, int relu, float *y, float *stats,
+                               void *ws, size_t ws_bytes, void *stream)
+{
+    BnRunning run = {nullptr, nullptr, nullptr, 0.f};
+    return bn_fwd_run(x, 0, k, c, gamma, beta, eps, relu, y, 0, stats, run, ws, ws_bytes, stream);
+}
+
+extern "C" int lcf_bn_relu_fwd_ex(const void *x, int x_bf16, int k, int c, const float *gamma,
+                                  const float *beta, float eps, int relu, void *y, int y_bf16,
+                                  float *stats, float *running_mean, float *running_var,
+                                  long long *num_batches_tracked, float momentum, void *ws,
+                                  size_t ws_bytes, void *stream)
+{
+    if ((running_mean == nullptr) != (running_var == nullptr)) return LCF_ERR_ARG;
+    BnRunning run = {running_mean, running_var, num_batches_tracked, momentum};
+    return bn_fwd_run(x, x_bf16, k, c, gamma, beta, eps, relu, y, y_bf16, stats, run, ws,
+                      ws_bytes, stream);
+}
+
+template <typename TX, typename TY, typename TG, typename TD>
+static int bn_bwd_launch(const void *x, const void *y, const void *dy, int k, int c,
+                         const float *gamma, const float *stats, int relu, void *dx,
+                         float *dgamma, float *dbeta, void *ws, hipStream_t st)
+{
+    int rpb, np;
+    bn_partition(k, &rpb, &np);
+    float *parts = (float *)ws;
+    double *sums = (double *)((char *)ws + (size_t)BN_MAX_PARTS * 2 * c * sizeof(float));
+    bn_bwd_reduce_kernel<TX, TY, TG><<<np, BN_BLOCK, 0, st>>>(
+        (const TX *)x, (const TY *)y, (const TG *)dy, k, c, rpb, stats, relu, parts);
+    LCF_CHECK_LAUNCH();
+    bn_finalize_kernel<<<2 * c, 64, 0, st>>>(parts, np, 2 * c, sums);
+    LCF_CHECK_LAUNCH();
+    bn_bwd_apply_kernel<TX, TY, TG, TD><<<np, BN_BLOCK, 0, st>>>(
+        (const TX *)x, (const TY *)y, (const TG *)dy, k, c, rpb, stats, sums, gamma, relu,
+        (TD *)dx, dgamma, dbeta);
+    LCF_CHECK_LAUNCH();
+    return LCF_OK;
+}
+
+extern "C" int lcf_bn_relu_bwd_ex(const void *x, int x_bf16, const void *y, int y_bf16,
+                                  const void *dy, int dy_bf16, int k, int c, const float *gamma,
+                                  const float *stats, int relu, void *dx, int dx_bf16,
+                                  float *dgamma, float *dbeta, void *ws, size_t ws_bytes,
+                                  void *stream)
 {
     int rc = bn_check(k, c);
     if (rc) return rc;
@@ -260,20 +368,32 @@ extern "C" int lcf_bn_relu_bwd(const float *x, const float *y, const float *dy, 
     if (((uintptr_t)x & 15) || ((uintptr_t)dy & 15) || ((uintptr_t)dx & 15) ||
         ((uintptr_t)y & 15) || ((uintptr_t)stats & 15))
         return LCF_ERR_ARG;
+    const int code = (x_bf16 ? 8 : 0) | (y_bf16 ? 4 : 0) | (dy_bf16 ? 2 : 0) | (dx_bf16 ? 1 : 0);
+    if (code && (c & 7)) return LCF_ERR_UNSUPPORTED;
     if (ws_bytes < lcf_bn_workspace_bytes(k, c)) return LCF_ERR_WORKSPACE;
-    int rpb, np;
-    bn_partition(k, &rpb, &np);
     hipStream_t st = (hipStream_t)stream;
-    float *parts = (float *)ws;
-    double *sums = (double *)((char *)ws + (size_t)BN_MAX_PARTS * 2 * c * sizeof(float));
-    bn_bwd_reduce_kernel<<<np, BN_BLOCK, 0, st>>>(x, y, dy, k, c, rpb, stats, relu, parts);
-    LCF_CHECK_LAUNCH();
-    bn_finalize_kernel<<<2 * c, 64, 0, st>>>(parts, np, 2 * c, sums);
-    LCF_CHECK_LAUNCH();
-    bn_bwd_apply_kernel<<<np, BN_BLOCK, 0, st>>>(x, y, dy, k, c, rpb, stats, sums, gamma, relu, dx,
-                                                dgamma, dbeta);
-    LCF_CHECK_LAUNCH();
-    return LCF_OK;
+    // the forms the training paths use: all fp32 (the module path); x fp32 with y / dy / dx in
+    // any mix of fp32 and bf16 (the fused conv + BN + ReLU step)
+    switch (code) {
+    case 0: return bn_bwd_launch<float, float, float, float>(x, y, dy, k, c, gamma, stats, relu, dx, dgamma, dbeta, ws, st);
+    case 1: return bn_bwd_launch<float, float, float, __bf16>(x, y, dy, k, c, gamma, stats, relu, dx, dgamma, dbeta, ws, st);
+    case 2: return bn_bwd_launch<float, float, __bf16, float>(x, y, dy, k, c, gamma, stats, relu, dx, dgamma, dbeta, ws, st);
+    case 3: return bn_bwd_launch<float, float, __bf16, __bf16>(x, y, dy, k, c, gamma, stats, relu, dx, dgamma, dbeta, ws, st);
+    case 4: return bn_bwd_launch<float, __bf16, float, float>(x, y, dy, k, c, gamma, stats, relu, dx, dgamma, dbeta, ws, st);
+    case 5: return bn_bwd_launch<float, __bf16, float, __bf16>(x, y, dy, k, c, gamma, stats, relu, dx, dgamma, dbeta, ws, st);
+    case 6: return bn_bwd_launch<float, __bf16, __bf16, float>(x, y, dy, k, c, gamma, stats, relu, dx, dgamma, dbeta, ws, st);
+    case 7: return bn_bwd_launch<float, __bf16, __bf16, __bf16>(x, y, dy, k, c, gamma, stats, relu, dx, dgamma, dbeta, ws, st);
+    default: return LCF_ERR_UNSUPPORTED; // bf16 x (conv outputs stay fp32)
+    }
+}
+
+extern "C" int lcf_bn_relu_bwd(const float *x, const float *y, const float *dy, int k, int c,
+                               const float *gamma, const float *stats, int relu, float *dx,
+                               float *dgamma, float *dbeta, void *ws, size_t ws_bytes,
+                               void *stream)
+{
+    return lcf_bn_relu_bwd_ex(x, 0, y, 0, dy, 0, k, c, gamma, stats, relu, dx, 0, dgamma, dbeta,
+                              ws, ws_bytes, stream);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -27,34 +27,87 @@ def shard_scenes(costs, world_size):
 
 
 class FlatGradAllReduce:
-    """All parameters' gradients live in ONE flat fp32 buffer (p.grad are views into it), so the
-    exchange step is a single all-reduce of ~7.4 MB for the SECOND front end + RPN instead of one
-    per tensor: over point-to-point xGMI links a ring all-reduce is latency-bound at this size and
-    one large message beats many small ones."""
+    """All parameters' gradients meet in ONE flat fp32 buffer, so the exchange step is a single
+    all-reduce of ~7.4 MB for the SECOND front end + RPN (or one per SEGMENT, see below) instead
+    of one per tensor: over point-to-point xGMI links a ring all-reduce is latency-bound at this
+    size and one large message beats many small ones.
 
-    def __init__(self, params, process_group=None):
-        self.params = [p for p in params if p.requires_grad]
+    Two ways of getting the gradients into the buffer:
+    * ``attach=True`` (round 1-2): p.grad ARE views into it; autograd then accumulates into
+      them, which costs one small add launch per parameter and step (120 launches, 0.46 ms of a
+      15.5 ms step on MI355X) plus the zero fill;
+    * ``attach=False`` (round 3, what TrainStep uses): p.grad is None before backward, autograd
+      hands every parameter its gradient tensor as produced (no launch), and ``collect()`` copies
+      them into the buffer with one multi-tensor copy per segment and re-points p.grad at the
+      views, so clipping, the all-reduce and the fused optimizer work on the flat buffer.
+
+    ``segments``: lists of parameters that become contiguous ranges of the buffer, each collected
+    and reduced on its own (``collect(i)``, ``reduce(i, async_op=True)``): the RPN's gradients
+    are complete when backward reaches the front end's output, so their all-reduce is launched
+    from a hook there and overlaps the front end's backward."""
+
+    def __init__(self, params, process_group=None, attach=True, segments=None):
+        if segments is None:
+            segments = [[p for p in params if p.requires_grad]]
+        else:
+            segments = [[p for p in seg if p.requires_grad] for seg in segments]
+        self.segments = segments
+        self.params = [p for seg in segments for p in seg]
         self.group = process_group
+        self.attach = attach
         n = sum(p.numel() for p in self.params)
         dev = self.params[0].device if self.params else torch.device("cpu")
         self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.views, self.ranges = [], []
         off = 0
-        for p in self.params:
-            seg = self.flat[off:off + p.numel()]
-            if p.is_contiguous():
-                p.grad = seg.view_as(p)
-            elif p.dim() == 4 and p.is_contiguous(memory_format=torch.channels_last):
-                # same physical order as the parameter (autograd's gradient layout contract):
-                # elementwise optimizer kernels then run on matching strides, and the fused
-                # multi-tensor AdamW accepts the pair
-                p.grad = seg.as_strided(p.size(), p.stride())
-            else:
-                raise ValueError("FlatGradAllReduce: parameters must be dense (contiguous or "
-                                 "channels_last)")
-            off += p.numel()
+        for seg in segments:
+            lo, vs = off, []
+            for p in seg:
+                piece = self.flat[off:off + p.numel()]
+                if p.is_contiguous():
+                    v = piece.view_as(p)
+                elif p.dim() == 4 and p.is_contiguous(memory_format=torch.channels_last):
+                    # same physical order as the parameter (autograd's gradient layout contract):
+                    # elementwise optimizer kernels then run on matching strides, and the fused
+                    # multi-tensor AdamW accepts the pair
+                    v = piece.as_strided(p.size(), p.stride())
+                else:
+                    raise ValueError("FlatGradAllReduce: parameters must be dense (contiguous or "
+                                     "channels_last)")
+                vs.append(v)
+                if attach:
+                    p.grad = v
+                off += p.numel()
+            self.views.append(vs)
+            self.ranges.append((lo, off))
+        self._pending = {}
 
     def zero(self):
-        self.flat.zero_()
+        """Start of a step: attached views are cleared; detached gradients are dropped so that
+        autograd installs the fresh tensors instead of adding into old ones."""
+        if self.attach:
+            self.flat.zero_()
+        else:
+            for p in self.params:
+                p.grad = None
+
+    def collect(self, segment=None):
+        """(attach=False) copy the gradients autograd produced into the flat buffer -- one
+        multi-tensor copy per segment -- and point p.grad at the views.  A parameter that got no
+        gradient this step contributes zeros."""
+        if self.attach:
+            return
+        for i in (range(len(self.segments)) if segment is None else [segment]):
+            src, dst = [], []
+            for p, v in zip(self.segments[i], self.views[i]):
+                if p.grad is None:
+                    v.zero_()
+                elif p.grad is not v:
+                    src.append(p.grad)
+                    dst.append(v)
+                p.grad = v
+            if src:
+                torch._foreach_copy_(dst, src)
 
     def clip_norm_(self, max_norm):
         """torch.nn.utils.clip_grad_norm_ over all parameters, on the flat buffer: the 2-norm of
@@ -63,20 +116,31 @@ class FlatGradAllReduce:
         self.flat.mul_(torch.clamp(max_norm / (total + 1e-6), max=1.0))
         return total
 
-    def reduce(self, async_op=False):
-        """Average gradients over ranks (sum, then divide by world size)."""
+    def reduce(self, segment=None, async_op=False):
+        """Average gradients over ranks (sum, then divide by world size): the whole buffer, or one
+        segment's range.  With async_op the collective's work handle is kept and ``wait()`` joins
+        every outstanding one (before clipping / the optimizer)."""
         if not (dist.is_available() and dist.is_initialized()):
             return None
         world = dist.get_world_size(self.group)
         if world == 1:
             return None
-        self.flat.div_(world)
-        if self.flat.is_cuda and dist.get_backend(self.group) == "gloo":
+        lo, hi = (0, self.flat.numel()) if segment is None else self.ranges[segment]
+        buf = self.flat[lo:hi]
+        buf.div_(world)
+        if buf.is_cuda and dist.get_backend(self.group) == "gloo":
             # rehearsal only (several ranks sharing one GPU over gloo): gloo's device path hangs
             # on large ROCm tensors, so stage through the host.  RCCL ("nccl") reduces in place.
-            host = self.flat.cpu()
+            host = buf.cpu()
             dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
-            self.flat.copy_(host)
+            buf.copy_(host)
             return None
-        return dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group,
-                               async_op=async_op)
+        work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
+        if async_op and work is not None:
+            self._pending[segment] = work
+        return work
+
+    def wait(self):
+        for work in self._pending.values():
+            work.wait()
+        self._pending.clear()

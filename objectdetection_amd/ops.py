@@ -797,21 +797,29 @@ def bn_relu_supported(x):
 
 class BNReLUFunction(torch.autograd.Function):
     """y = relu(batch_norm(x)) with batch statistics over the rows of x [K, C] (include/lcf.h:
-    lcf_bn_relu_fwd / _bwd).  Returns (y, mean, biased var); the module updates its running
-    statistics from the latter two."""
+    lcf_bn_relu_fwd_ex / _bwd_ex).  Returns (y, stats = mean | biased var | inv); with ``run`` =
+    (running_mean, running_var, num_batches_tracked, momentum) the forward kernel also updates the
+    module's running statistics.  ``y_bf16``: y is stored (and returned) as bf16 -- the input of a
+    bf16 MFMA sparse conv, which gathers it -- and the gradient arrives as bf16 too."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps, relu):
+    def forward(ctx, x, gamma, beta, eps, relu, run=None, y_bf16=False):
         L = _lib.lib()
         x = x.contiguous()
         k, c = x.shape
-        y = torch.empty_like(x)
+        y = torch.empty((k, c), dtype=torch.bfloat16 if y_bf16 else torch.float32,
+                        device=x.device)
         stats = torch.empty((3 * c,), dtype=torch.float32, device=x.device)
         ws = _ws(L.lcf_bn_workspace_bytes(k, c), x.device)
         g = None if gamma is None else gamma.detach().float().contiguous()
         b = None if beta is None else beta.detach().float().contiguous()
-        check(L.lcf_bn_relu_fwd(_ptr(x), k, c, _ptr(g), _ptr(b), float(eps), int(relu), _ptr(y),
-                                _ptr(stats), _ptr(ws), ws.numel(), _stream()))
+        rm = rv = nbt = None
+        mom = 0.0
+        if run is not None:
+            rm, rv, nbt, mom = run
+        check(L.lcf_bn_relu_fwd_ex(_ptr(x), 0, k, c, _ptr(g), _ptr(b), float(eps), int(relu),
+                                   _ptr(y), int(bool(y_bf16)), _ptr(stats), _ptr(rm), _ptr(rv),
+                                   _ptr(nbt), float(mom), _ptr(ws), ws.numel(), _stream()))
         ctx.save_for_backward(x, y, g, stats)
         ctx.relu = bool(relu)
         ctx.has = (gamma is not None, beta is not None)
@@ -824,14 +832,17 @@ class BNReLUFunction(torch.autograd.Function):
         x, y, g, stats = ctx.saved_tensors
         k, c = x.shape
         dy = dy.contiguous()
+        if dy.dtype not in (torch.float32, torch.bfloat16):
+            dy = dy.float()
         dx = torch.empty_like(x)
         dg = torch.empty((c,), dtype=torch.float32, device=x.device) if ctx.has[0] else None
         db = torch.empty((c,), dtype=torch.float32, device=x.device) if ctx.has[1] else None
         ws = _ws(L.lcf_bn_workspace_bytes(k, c), x.device)
-        check(L.lcf_bn_relu_bwd(_ptr(x), _ptr(y), _ptr(dy), k, c, _ptr(g), _ptr(stats),
-                                int(ctx.relu), _ptr(dx), _ptr(dg), _ptr(db), _ptr(ws), ws.numel(),
-                                _stream()))
-        return dx, dg, db, None, None
+        check(L.lcf_bn_relu_bwd_ex(_ptr(x), 0, _ptr(y), int(y.dtype == torch.bfloat16), _ptr(dy),
+                                   int(dy.dtype == torch.bfloat16), k, c, _ptr(g), _ptr(stats),
+                                   int(ctx.relu), _ptr(dx), 0, _ptr(dg), _ptr(db), _ptr(ws),
+                                   ws.numel(), _stream()))
+        return dx, dg, db, None, None, None, None
 
 
 class AffineReluSegMaxFunction(torch.autograd.Function):
@@ -954,11 +965,27 @@ def vfe_layer_train(x, xp, wp, seg, norm, n, k, mode):
     return out
 
 
-def bn_relu_train(norm, x, relu=True):
-    """nn.BatchNorm1d `norm` in training mode (+ ReLU) on x [K, C]: the fused kernels, then the
-    running-statistics update nn.BatchNorm1d would have done (unbiased variance, momentum)."""
-    y, stats = BNReLUFunction.apply(x, norm.weight, norm.bias, norm.eps, relu)
-    if norm.track_running_stats:
+def _bn_running(norm):
+    """(running_mean, running_var, num_batches_tracked, momentum) for the kernels that update the
+    running statistics themselves, or None (no tracking, cumulative averaging, non-fp32 buffers:
+    the caller then updates them with torch ops)."""
+    if not norm.track_running_stats or norm.momentum is None or norm.running_mean is None:
+        return None
+    rm, rv, nbt = norm.running_mean, norm.running_var, norm.num_batches_tracked
+    if rm.dtype != torch.float32 or rv.dtype != torch.float32 or not rm.is_cuda or \
+            not rm.is_contiguous() or not rv.is_contiguous():
+        return None
+    if nbt is not None and nbt.dtype != torch.int64:
+        return None
+    return rm, rv, nbt, float(norm.momentum)
+
+
+def bn_relu_train(norm, x, relu=True, y_bf16=False):
+    """nn.BatchNorm1d `norm` in training mode (+ ReLU) on x [K, C]: the fused kernels, including
+    the running-statistics update nn.BatchNorm1d would have done (unbiased variance, momentum)."""
+    run = _bn_running(norm)
+    y, stats = BNReLUFunction.apply(x, norm.weight, norm.bias, norm.eps, relu, run, y_bf16)
+    if norm.track_running_stats and run is None:
         with torch.no_grad():
             k, c = x.shape
             norm.num_batches_tracked += 1

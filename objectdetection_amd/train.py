@@ -26,8 +26,17 @@ class Detector(nn.Module):
         if rpn_bf16:  # dense() lands in the RPN's input layout and dtype in one pass
             self.frontend.middle_feature_extractor.dense_to = "rpn_bf16"
 
+    # called (no arguments) when backward has produced the gradient of the front end's output,
+    # i.e. when every RPN parameter's gradient is complete (TrainStep: async all-reduce of them)
+    on_rpn_grads_ready = None
+
     def forward(self, clouds):
         x = self.frontend(clouds)
+        if self.on_rpn_grads_ready is not None and x.requires_grad:
+            def _hook(g, cb=self.on_rpn_grads_ready):
+                cb()
+                return g
+            x.register_hook(_hook)
         if not (self.rpn_bf16 and x.is_cuda):
             return self.rpn(x)
         with torch.autocast("cuda", dtype=torch.bfloat16):
@@ -61,7 +70,7 @@ class TrainStep:
     """Owns the model, the flat gradient bucket and the optimizer of ONE rank."""
 
     def __init__(self, device, model="M2", lr=3e-4, seed=0, process_group=None,
-                 conv_math="bf16", freeze_gc_after=5):
+                 conv_math="bf16", freeze_gc_after=5, overlap_allreduce=True):
         # conv_math "bf16": indice_conv forward + dgrad with bf16 MFMA operands and fp32
         # accumulation (BASELINE.json configs[2]); fp32 master weights, fp32 wgrad.
         self.device = device
@@ -71,7 +80,17 @@ class TrainStep:
         torch.backends.cudnn.benchmark = True
         self.net = randomize_(Detector(model), seed).to(device).train()
         self.net.rpn.to(memory_format=torch.channels_last)
-        self.bucket = FlatGradAllReduce(self.net.parameters(), process_group)
+        # gradients: produced by autograd as fresh tensors and gathered into ONE flat buffer with a
+        # multi-tensor copy per segment (dist.py).  Two segments -- front end | RPN: the RPN's
+        # gradients are complete first (backward runs the RPN first), so with more than one rank
+        # their all-reduce starts from a hook at the front end's output and overlaps the front
+        # end's backward; the front end's follows behind backward
+        self.bucket = FlatGradAllReduce(
+            None, process_group, attach=False,
+            segments=[list(self.net.frontend.parameters()), list(self.net.rpn.parameters())])
+        self.overlap_allreduce = overlap_allreduce
+        if overlap_allreduce and self._world() > 1:
+            self.net.on_rpn_grads_ready = self._rpn_grads_ready
         # fused: one multi-tensor kernel per step instead of ~8 launches per parameter (78
         # parameters: 0.8 ms of a 19 ms step); gradients share their parameter's layout (dist.py)
         self.opt = torch.optim.AdamW(self.net.parameters(), lr=lr, weight_decay=0.01,
@@ -85,6 +104,16 @@ class TrainStep:
         self.freeze_gc_after = freeze_gc_after
         self.calls = 0
 
+    def _world(self):
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()):
+            return 1
+        return dist.get_world_size(self.bucket.group)
+
+    def _rpn_grads_ready(self):
+        self.bucket.collect(1)
+        self.bucket.reduce(1, async_op=True)
+
     def __call__(self, clouds):
         """clouds: this rank's scenes (list of [N,4] cuda tensors) -> loss (device scalar)."""
         from . import ops
@@ -97,7 +126,13 @@ class TrainStep:
         with ops.conv_math(self.conv_math):
             loss = synthetic_loss(self.net(clouds), self.gen)
             loss.backward()
-        self.bucket.reduce()
+        if self.net.on_rpn_grads_ready is not None:
+            self.bucket.collect(0)
+            self.bucket.reduce(0)
+            self.bucket.wait()
+        else:
+            self.bucket.collect()
+            self.bucket.reduce()
         self.bucket.clip_norm_(10.0)  # clip_grad_norm_(parameters, 10.0), train.py:342
         self.opt.step()
         return loss.detach()

@@ -42,12 +42,26 @@ def test_main_becomes_the_launcher_only_without_world_size(monkeypatch):
     monkeypatch.setattr(bench, "launch_ranks", lambda n, argv, script=None: calls.append(
         (n, list(argv))) or 0)
     monkeypatch.delenv("WORLD_SIZE", raising=False)
-    monkeypatch.setenv("LCF_REHEARSE", "1")  # skips the visible-GPU count check
+    monkeypatch.delenv("LCF_REHEARSE", raising=False)
+    # the launcher makes no GPU call of any kind (not even a device count): a process that has
+    # initialised HIP must not start other GPU programs on this pool
+    import torch
+
+    def forbidden(*a, **k):
+        raise AssertionError("the launcher touched torch.cuda")
+    monkeypatch.setattr(torch.cuda, "device_count", forbidden)
+    monkeypatch.setattr(torch.cuda, "is_available", forbidden)
     assert bench.main(["--gpus", "2", "--steps", "5", "--warmup", "1"]) == 0
     assert calls == [(2, ["--gpus", "2", "--steps", "5", "--warmup", "1"])]
-    # fewer visible GPUs than asked for, not a rehearsal: a clear refusal, nothing launched
-    monkeypatch.delenv("LCF_REHEARSE")
-    calls.clear()
+
+
+def test_a_rank_without_a_device_refuses_with_exit_code_2(monkeypatch, capsys):
+    """The visible-GPU check lives in the child ranks: LOCAL_RANK >= device count -> exit code 2
+    and a message, before any process group is set up."""
     import torch
-    if torch.cuda.device_count() < 64:
-        assert bench.main(["--gpus", "64"]) == 2 and calls == []
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    monkeypatch.setenv("RANK", "0")
+    monkeypatch.setenv("LOCAL_RANK", str(torch.cuda.device_count() + 3))
+    monkeypatch.delenv("LCF_REHEARSE", raising=False)
+    assert bench.main(["--gpus", "1", "--steps", "1", "--warmup", "0"]) == 2
+    assert "has no GPU" in capsys.readouterr().err

@@ -124,3 +124,78 @@ def test_shard_scenes_balances_cost():
     assert max(loads) - min(loads) <= 20
     assert shard_scenes([1, 1, 1, 1], 4) == [[0], [1], [2], [3]]
     assert [len(s) for s in shard_scenes([5] * 64, 8)] == [8] * 8
+
+
+def _segmented_worker(rank, world, port, q):
+    """TrainStep's exchange (round 3): gradients produced by autograd as fresh tensors, gathered
+    per segment (front | back of a small two-stage net) into the flat buffer, the back segment
+    all-reduced ASYNCHRONOUSLY from a hook at the stage boundary while backward continues, the
+    front segment behind backward, wait() before use -- against the blocking whole-buffer form."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    out = []
+    for mode in ("blocking", "overlap"):
+        torch.manual_seed(0)
+        front = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.ReLU())
+        back = torch.nn.Sequential(torch.nn.Linear(16, 16), torch.nn.ReLU(), torch.nn.Linear(16, 4))
+        bucket = FlatGradAllReduce(None, attach=False,
+                                   segments=[list(front.parameters()), list(back.parameters())])
+        data = torch.arange(4 * 8, dtype=torch.float32).view(4, 8) / 10 + rank
+        fired = []
+        for step in range(2):  # the second step checks that stale views are not accumulated into
+            bucket.zero()
+            assert all(p.grad is None for p in bucket.params)
+            h = front(data)
+            if mode == "overlap":
+                def hook(g):
+                    bucket.collect(1)
+                    bucket.reduce(1, async_op=True)
+                    fired.append(1)
+                    return g
+                h.register_hook(hook)
+            (back(h) ** 2).sum().backward()
+            if mode == "overlap":
+                bucket.collect(0)
+                bucket.reduce(0)
+                bucket.wait()
+            else:
+                bucket.collect()
+                bucket.reduce()
+        assert mode == "blocking" or len(fired) == 2
+        views_ok = all(p.grad.untyped_storage().data_ptr() == bucket.flat.untyped_storage().data_ptr()
+                       for p in bucket.params)
+        out.append((bucket.flat.clone(), views_ok))
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_overlapped_segment_allreduce_equals_blocking_world2():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_segmented_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (b0, ok0), (o0, ok1) = res[0][1]
+    (b1, _), (o1, _) = res[1][1]
+    assert ok0 and ok1
+    assert torch.equal(b0, b1) and torch.equal(o0, o1)   # ranks agree
+    assert torch.equal(b0, o0)                            # overlapped == blocking, bit for bit
+    # and equals the single-process average of the two ranks' gradients
+    ref = []
+    for rank in range(world):
+        torch.manual_seed(0)
+        front = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.ReLU())
+        back = torch.nn.Sequential(torch.nn.Linear(16, 16), torch.nn.ReLU(), torch.nn.Linear(16, 4))
+        data = torch.arange(4 * 8, dtype=torch.float32).view(4, 8) / 10 + rank
+        (back(front(data)) ** 2).sum().backward()
+        ref.append(torch.cat([p.grad.flatten() for p in list(front.parameters()) +
+                              list(back.parameters())]))
+    assert torch.allclose(b0, (ref[0] + ref[1]) / world, rtol=1e-5, atol=1e-6)
