@@ -395,6 +395,26 @@ int lcf_indice_conv_wgrad_bf16(const float *feat, const float *dout, const int *
                                int kvol, int cin, int cout, int planes, float *dw,
                                void *stream);
 
+/* indice_conv for the training step on rows STORED as bf16 (round 3; BASELINE.json configs[2]).
+ * Replaces the same reference calls as lcf_indice_conv_fwd / _wgrad (indice_conv and
+ * indice_conv_backward inside spconv's SparseConvolution, second/pytorch/models/middle.py:145-192)
+ * when the activations a conv gathers have been written as bf16 by their producer
+ * (lcf_bn_relu_fwd_ex / _bwd_ex): gathered rows are 128 bytes at 64 channels, operands go to
+ * v_mfma_f32_16x16x32_bf16 without conversion, accumulation is fp32.
+ * fwd_b16: feat [k_in,cin] bf16, wimg = lcf_weight_image_bf16, nbr [k_out,kvol]; out [k_out,cout]
+ *   fp32 (out_bf16 = 0) or bf16 rounded to nearest even (1).  dgrad: the same call over in_nbr
+ *   with the transposed image and cin / cout exchanged.  cin, cout in {32, 64, 128}.  No BatchNorm
+ *   epilogue (training BatchNorm needs the batch statistics of `out` first).  Deterministic.
+ * wgrad_b16: feat [k_in,cin] bf16, dout [k_out,cout] bf16, in_nbr [k_in,kvol] -> dw
+ *   [kvol,cin,cout] fp32 (zeroed inside; fp32 atomics across workgroups); cin, cout in {32, 64}.
+ * Stated tolerance of the bf16 forms: 2e-2 of the result's max magnitude against the fp32
+ * oracle (operands carry 8 significand bits); measured in tests/test_gpu_conv.py. */
+int lcf_indice_conv_fwd_b16(const void *feat_bf16, const void *wimg_bf16, const int *nbr,
+                            int k_out, int kvol, int cin, int cout, void *out, int out_bf16,
+                            void *stream);
+int lcf_indice_conv_wgrad_b16(const void *feat_bf16, const void *dout_bf16, const int *in_nbr,
+                              int k_in, int kvol, int cin, int cout, float *dw, void *stream);
+
 /* Frame hand-over for a caller that keeps a static point buffer and a device-side point count
  * (FrameEngine; no counterpart in the reference): dst[0 : n*f] = points[0 : n*f] and
  * n_dev[0] = n_total (>= n: dst may point behind points already in the buffer, the light-curtain
@@ -456,6 +476,14 @@ int lcf_dense_nhwc_bf16(const float *feat, const int *coors, int k, const int *k
                         void *stream);
 int lcf_dense_nhwc_bf16_bwd(const void *dout_bf16, const int *coors, int k, int c, int batch,
                             const int shape[3], float *dfeat, void *stream);
+/* The same pair with the feature rows (feat / dfeat) stored as fp32 (0) or bf16 (1): the bf16
+ * training path hands its last layer's bf16 rows over as they are and takes the gradient back as
+ * bf16 rows. */
+int lcf_dense_nhwc_bf16_rows(const void *feat, int feat_bf16, const int *coors, int k,
+                             const int *k_dev, int c, int batch, const int shape[3],
+                             int zero_fill, void *out_bf16, void *stream);
+int lcf_dense_nhwc_bf16_bwd_rows(const void *dout_bf16, const int *coors, int k, int c, int batch,
+                                 const int shape[3], void *dfeat, int dfeat_bf16, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * VFE streaming kernels (second/pytorch/models/voxel_encoder.py).

@@ -117,6 +117,14 @@ SYMBOLS = {
     "lcf_linear_wgrad": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "lcf_indice_conv_wgrad_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                            c_int, c_int, c_void_p, c_void_p]),
+    "lcf_indice_conv_fwd_b16": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                        c_void_p, c_int, c_void_p]),
+    "lcf_indice_conv_wgrad_b16": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                          c_int, c_void_p, c_void_p]),
+    "lcf_dense_nhwc_bf16_rows": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int,
+                                         _PI3, c_int, c_void_p, c_void_p]),
+    "lcf_dense_nhwc_bf16_bwd_rows": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, _PI3,
+                                             c_void_p, c_int, c_void_p]),
     "lcf_load_points": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     "lcf_dense": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, _PI3, c_int,
                           c_void_p, c_void_p]),

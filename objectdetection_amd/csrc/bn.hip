@@ -46,13 +46,6 @@ __device__ __forceinline__ float4 bn_ld4(const T *row, int c4)
     }
 }
 
-__device__ __forceinline__ unsigned bn_bf16_rne(float f)
-{
-    unsigned u = __float_as_uint(f);
-    if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (u >> 16) | 0x40u; // NaN stays NaN
-    return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;                  // round to nearest even
-}
-
 template <typename T>
 __device__ __forceinline__ void bn_st4(T *row, int c4, float4 v)
 {
@@ -60,8 +53,8 @@ __device__ __forceinline__ void bn_st4(T *row, int c4, float4 v)
         reinterpret_cast<float4 *>(row)[c4] = v;
     } else {
         uint2 u;
-        u.x = bn_bf16_rne(v.x) | (bn_bf16_rne(v.y) << 16);
-        u.y = bn_bf16_rne(v.z) | (bn_bf16_rne(v.w) << 16);
+        u.x = lcf_bf16_rne(v.x) | (lcf_bf16_rne(v.y) << 16);
+        u.y = lcf_bf16_rne(v.z) | (lcf_bf16_rne(v.w) << 16);
         reinterpret_cast<uint2 *>(row)[c4] = u;
     }
 }

@@ -110,6 +110,14 @@ __device__ __forceinline__ int lcf_count(int cap, const int *dev)
     return v < cap ? v : cap;
 }
 
+// fp32 -> bf16 bits, round to nearest even (NaN stays NaN): what torch's float -> bfloat16 copy does
+__device__ __forceinline__ unsigned lcf_bf16_rne(float f)
+{
+    unsigned u = __float_as_uint(f);
+    if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (u >> 16) | 0x40u;
+    return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+
 // 32-bit integer hash (murmur3 finaliser)
 __device__ __forceinline__ uint32_t lcf_hash32(uint32_t h)
 {

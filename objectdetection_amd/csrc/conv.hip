@@ -2010,6 +2010,8 @@ cv_wgrad_mc_kernel(const float *__restrict__ feat, const float *__restrict__ dou
     for (int e = tid; e < CIN * COUT; e += 256) atomicAdd(&dwo[e], red[e]);
 }
 
+#include "conv_bt.h" // bf16-row training kernels (forward / dgrad / wgrad), round 3
+
 // -------------------------------------------------------------------------- host side
 
 extern "C" size_t lcf_weight_image_elems(int kvol, int cin, int cout, int transpose)
@@ -2302,6 +2304,44 @@ extern "C" int lcf_indice_conv_wgrad_bf16(const float *feat, const float *dout,
 }
 
 // cols columns of dout / dW[o] starting at the given pointers, rows ld floats apart
+template <int CIN, int COUT>
+static int cv_launch_wgrad_b16(const void *feat, const void *dout, const int *in_nbr, int k_in,
+                               int kvol, float *dw, hipStream_t st)
+{
+    if (lcf_fill32(dw, 0u, (size_t)kvol * CIN * COUT * 4, st) != LCF_OK) return LCF_ERR_LAUNCH;
+    if (k_in == 0) return LCF_OK;
+    long long want = ((long long)k_in * kvol + 2999) / 3000; // ~3000 workgroups, as the mc form
+    int wg_rows = (int)((want + 255) / 256 * 256);
+    if (wg_rows < 256) wg_rows = 256;
+    if (wg_rows > 16384) wg_rows = 16384;
+    const int nchunk = (k_in + wg_rows - 1) / wg_rows;
+    const unsigned grid = (unsigned)(8 * ((nchunk + 7) / 8) * kvol);
+    cv_wgrad_b16_kernel<CIN, COUT><<<grid, 256, 0, st>>>(
+        (const __bf16 *)feat, (const __bf16 *)dout, in_nbr, k_in, kvol, wg_rows, dw);
+    LCF_CHECK_LAUNCH();
+    return LCF_OK;
+}
+
+extern "C" int lcf_indice_conv_wgrad_b16(const void *feat_bf16, const void *dout_bf16,
+                                         const int *in_nbr, int k_in, int kvol, int cin, int cout,
+                                         float *dw, void *stream)
+{
+    if (k_in < 0 || kvol <= 0 || kvol > LCF_MAX_KVOL || !dw || !in_nbr ||
+        (k_in > 0 && (!feat_bf16 || !dout_bf16)))
+        return LCF_ERR_ARG;
+    if (((uintptr_t)feat_bf16 & 15) || ((uintptr_t)dout_bf16 & 15)) return LCF_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+#define WB_CASE(A, B) \
+    if (cin == A && cout == B) \
+        return cv_launch_wgrad_b16<A, B>(feat_bf16, dout_bf16, in_nbr, k_in, kvol, dw, st)
+    WB_CASE(32, 32);
+    WB_CASE(32, 64);
+    WB_CASE(64, 32);
+    WB_CASE(64, 64);
+#undef WB_CASE
+    return LCF_ERR_UNSUPPORTED;
+}
+
 static int cv_wgrad_cols(const float *feat, const float *dout, const int *in_nbr, int k_in, int kvol,
                          int cin, int cols, int ld, float *dw, hipStream_t st)
 {

@@ -409,8 +409,9 @@ extern "C" int lcf_dense_bwd(const float *dout, const int *coors, int k, int c, 
 // element (b, c, z, y, x) at ((b*H + y)*W + x)*(C*D) + c*D + z.  One pass instead of fp32 NCDHW
 // scatter + layout copy + dtype copy (and half the zero fill); the two z-rows of a pillar fill
 // one 2*C*D-byte run.  Rounding: round-to-nearest-even, as torch's float -> bfloat16 copy.
+template <typename TF>
 __global__ void __launch_bounds__(256)
-dense_nhwc_bf16_kernel(const float *__restrict__ feat, const int *__restrict__ coors, int k_cap,
+dense_nhwc_bf16_kernel(const TF *__restrict__ feat, const int *__restrict__ coors, int k_cap,
                        const int *__restrict__ k_dev, int c, int batch, int D, int H, int W,
                        __bf16 *__restrict__ out)
 {
@@ -423,13 +424,14 @@ dense_nhwc_bf16_kernel(const float *__restrict__ feat, const int *__restrict__ c
         q.w >= W)
         return;
     size_t pix = ((size_t)q.x * H + q.z) * W + q.w;
-    out[pix * ((size_t)c * D) + (size_t)ch * D + q.y] = (__bf16)feat[t];
+    out[pix * ((size_t)c * D) + (size_t)ch * D + q.y] = (__bf16)(float)feat[t];
 }
 
+template <typename TF>
 __global__ void __launch_bounds__(256)
 dense_nhwc_bf16_gather_kernel(const __bf16 *__restrict__ dout, const int *__restrict__ coors,
                               int k, int c, int batch, int D, int H, int W,
-                              float *__restrict__ dfeat)
+                              TF *__restrict__ dfeat)
 {
     long long t = (long long)blockIdx.x * 256 + threadIdx.x;
     if (t >= (long long)k * c) return;
@@ -441,12 +443,31 @@ dense_nhwc_bf16_gather_kernel(const __bf16 *__restrict__ dout, const int *__rest
         size_t pix = ((size_t)q.x * H + q.z) * W + q.w;
         v = (float)dout[pix * ((size_t)c * D) + (size_t)ch * D + q.y];
     }
-    dfeat[t] = v;
+    dfeat[t] = (TF)v;
 }
+
+static int dense_nhwc_run(const void *feat, int feat_bf16, const int *coors, int k,
+                          const int *k_dev, int c, int batch, const int shape[3], int zero_fill,
+                          void *out_bf16, void *stream);
 
 extern "C" int lcf_dense_nhwc_bf16(const float *feat, const int *coors, int k, const int *k_dev,
                                    int c, int batch, const int shape[3], int zero_fill,
                                    void *out_bf16, void *stream)
+{
+    return dense_nhwc_run(feat, 0, coors, k, k_dev, c, batch, shape, zero_fill, out_bf16, stream);
+}
+
+extern "C" int lcf_dense_nhwc_bf16_rows(const void *feat, int feat_bf16, const int *coors, int k,
+                                        const int *k_dev, int c, int batch, const int shape[3],
+                                        int zero_fill, void *out_bf16, void *stream)
+{
+    return dense_nhwc_run(feat, feat_bf16, coors, k, k_dev, c, batch, shape, zero_fill, out_bf16,
+                          stream);
+}
+
+static int dense_nhwc_run(const void *feat, int feat_bf16, const int *coors, int k,
+                          const int *k_dev, int c, int batch, const int shape[3], int zero_fill,
+                          void *out_bf16, void *stream)
 {
     if (k < 0 || c <= 0 || batch <= 0 || !shape || !out_bf16 || (k > 0 && (!feat || !coors)))
         return LCF_ERR_ARG;
@@ -456,8 +477,36 @@ extern "C" int lcf_dense_nhwc_bf16(const float *feat, const int *coors, int k, c
     if (zero_fill && lcf_fill32(out_bf16, 0u, bytes, st) != LCF_OK) return LCF_ERR_LAUNCH;
     if (k == 0) return LCF_OK;
     long long total = (long long)k * c;
-    dense_nhwc_bf16_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(
-        feat, coors, k, k_dev, c, batch, shape[0], shape[1], shape[2], (__bf16 *)out_bf16);
+    const unsigned grid = (unsigned)((total + 255) / 256);
+    if (feat_bf16)
+        dense_nhwc_bf16_kernel<__bf16><<<grid, 256, 0, st>>>(
+            (const __bf16 *)feat, coors, k, k_dev, c, batch, shape[0], shape[1], shape[2],
+            (__bf16 *)out_bf16);
+    else
+        dense_nhwc_bf16_kernel<float><<<grid, 256, 0, st>>>(
+            (const float *)feat, coors, k, k_dev, c, batch, shape[0], shape[1], shape[2],
+            (__bf16 *)out_bf16);
+    LCF_CHECK_LAUNCH();
+    return LCF_OK;
+}
+
+extern "C" int lcf_dense_nhwc_bf16_bwd_rows(const void *dout_bf16, const int *coors, int k, int c,
+                                            int batch, const int shape[3], void *dfeat,
+                                            int dfeat_bf16, void *stream)
+{
+    if (k < 0 || c <= 0 || batch <= 0 || !shape || !dout_bf16 || (k > 0 && (!dfeat || !coors)))
+        return LCF_ERR_ARG;
+    if (k == 0) return LCF_OK;
+    long long total = (long long)k * c;
+    const unsigned grid = (unsigned)((total + 255) / 256);
+    if (dfeat_bf16)
+        dense_nhwc_bf16_gather_kernel<__bf16><<<grid, 256, 0, (hipStream_t)stream>>>(
+            (const __bf16 *)dout_bf16, coors, k, c, batch, shape[0], shape[1], shape[2],
+            (__bf16 *)dfeat);
+    else
+        dense_nhwc_bf16_gather_kernel<float><<<grid, 256, 0, (hipStream_t)stream>>>(
+            (const __bf16 *)dout_bf16, coors, k, c, batch, shape[0], shape[1], shape[2],
+            (float *)dfeat);
     LCF_CHECK_LAUNCH();
     return LCF_OK;
 }
@@ -465,15 +514,7 @@ extern "C" int lcf_dense_nhwc_bf16(const float *feat, const int *coors, int k, c
 extern "C" int lcf_dense_nhwc_bf16_bwd(const void *dout_bf16, const int *coors, int k, int c,
                                        int batch, const int shape[3], float *dfeat, void *stream)
 {
-    if (k < 0 || c <= 0 || batch <= 0 || !shape || !dout_bf16 || (k > 0 && (!dfeat || !coors)))
-        return LCF_ERR_ARG;
-    if (k == 0) return LCF_OK;
-    long long total = (long long)k * c;
-    dense_nhwc_bf16_gather_kernel<<<(unsigned)((total + 255) / 256), 256, 0,
-                                    (hipStream_t)stream>>>(
-        (const __bf16 *)dout_bf16, coors, k, c, batch, shape[0], shape[1], shape[2], dfeat);
-    LCF_CHECK_LAUNCH();
-    return LCF_OK;
+    return lcf_dense_nhwc_bf16_bwd_rows(dout_bf16, coors, k, c, batch, shape, dfeat, 0, stream);
 }
 
 // ---------------------------------------------------------------- VFE

@@ -117,6 +117,8 @@ class _MiddleBase(nn.Module):
     def forward(self, voxel_features, coors, batch_size):
         coors = coors.int()
         ret = spconv.SparseConvTensor(voxel_features, coors, self.sparse_shape, batch_size)
+        # the bf16 hand-over below takes the last layer's rows as bf16 (no fp32 copy of them)
+        self.middle_conv.tail_takes_bf16 = self.dense_to == "rpn_bf16" and voxel_features.is_cuda
         ret = self.middle_conv(ret)
         if self.dense_to == "rpn_bf16" and ret.features.is_cuda:
             # straight into the RPN's channels_last bf16 input (no fp32 NCDHW tensor in between)

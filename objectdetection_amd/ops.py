@@ -672,6 +672,133 @@ def indice_conv(features, weight, rulebook):
     return IndiceConvFunction.apply(features, weight, rulebook)
 
 
+# ------------------------------------------------------------------ bf16-row training convs
+
+def conv_forward_b16(features, wimg, nbr, n_rows, kvol, cin, cout, out_bf16=False):
+    """indice_conv over rows STORED as bf16 (include/lcf.h: lcf_indice_conv_fwd_b16): features
+    [k_in, cin] bfloat16, wimg = weight_image_bf16 -> [n_rows, cout] float32, or bfloat16 with
+    ``out_bf16`` (dgrad: pass in_nbr, the transposed image and cin / cout exchanged)."""
+    _need_cuda(features, wimg, nbr)
+    if features.dtype != torch.bfloat16:
+        raise ValueError("conv_forward_b16 takes bfloat16 rows")
+    x = features.contiguous()
+    out = torch.empty((int(n_rows), int(cout)),
+                      dtype=torch.bfloat16 if out_bf16 else torch.float32, device=x.device)
+    check(_lib.lib().lcf_indice_conv_fwd_b16(_ptr(x), _ptr(wimg), _ptr(nbr), int(n_rows),
+                                             int(kvol), int(cin), int(cout), _ptr(out),
+                                             int(bool(out_bf16)), _stream()))
+    return out
+
+
+def conv_wgrad_b16(features, dout, in_nbr, kvol, cin, cout):
+    """dw [kvol, cin, cout] float32 from bfloat16 rows (lcf_indice_conv_wgrad_b16)."""
+    _need_cuda(features, dout, in_nbr)
+    if features.dtype != torch.bfloat16 or dout.dtype != torch.bfloat16:
+        raise ValueError("conv_wgrad_b16 takes bfloat16 rows")
+    x, g = features.contiguous(), dout.contiguous()
+    dw = torch.empty((int(kvol), int(cin), int(cout)), dtype=torch.float32, device=x.device)
+    check(_lib.lib().lcf_indice_conv_wgrad_b16(_ptr(x), _ptr(g), _ptr(in_nbr), x.shape[0],
+                                               int(kvol), int(cin), int(cout), _ptr(dw),
+                                               _stream()))
+    return dw
+
+
+def b16_conv_supported(cin, cout):
+    """Channel pairs the bf16-row training kernels (forward, dgrad and wgrad) are built for."""
+    return cin in (32, 64) and cout in (32, 64)
+
+
+class ConvBNReLUTrainFunction(torch.autograd.Function):
+    """One ``sparse conv -> BatchNorm1d (training) -> ReLU`` triple of the middle extractor as ONE
+    autograd node on bf16 rows (BASELINE.json configs[2]; second/pytorch/models/middle.py:145-192
+    in training mode, second/pytorch/train.py:316-343).
+
+    The tensors a sparse conv GATHERS -- its input y_prev and, in backward, the gradient of its own
+    output -- are bf16 rows (128 bytes at 64 channels), written once by the BatchNorm kernels;
+    the conv output x stays fp32 (BatchNorm statistics and its backward need it) and never leaves
+    this node, so autograd's dtype rules do not force fp32 onto the gathered gradients.
+        forward : x = conv(y_prev) [fp32] ; y = relu(bn(x)) [bf16 or fp32]
+        backward: dx = bn_relu_bwd(x, y, dy) [bf16] ; dy_prev = dgrad(dx) [bf16] ; dW = wgrad
+    Same arithmetic as IndiceConvFunction + BNReLUFunction under conv_math("bf16") in forward and
+    dgrad (those round the same operands to bf16 when they enter LDS); the weight gradient takes
+    its operands at bf16 as well (the split hi + lo form needs fp32 rows)."""
+
+    @staticmethod
+    def forward(ctx, feats, weight, gamma, beta, rulebook, eps, relu, run, y_bf16):
+        L = _lib.lib()
+        cin, cout = int(weight.shape[-2]), int(weight.shape[-1])
+        rb = rulebook
+        x = conv_forward_b16(feats, weight_image_bf16(weight), rb.out_nbr, rb.k_out, rb.kvol,
+                             cin, cout)
+        k = x.shape[0]
+        y = torch.empty((k, cout), dtype=torch.bfloat16 if y_bf16 else torch.float32,
+                        device=x.device)
+        stats = torch.empty((3 * cout,), dtype=torch.float32, device=x.device)
+        ws = _ws(L.lcf_bn_workspace_bytes(k, cout), x.device)
+        g = None if gamma is None else gamma.detach().float().contiguous()
+        b = None if beta is None else beta.detach().float().contiguous()
+        rm = rv = nbt = None
+        mom = 0.0
+        if run is not None:
+            rm, rv, nbt, mom = run
+        check(L.lcf_bn_relu_fwd_ex(_ptr(x), 0, k, cout, _ptr(g), _ptr(b), float(eps), int(relu),
+                                   _ptr(y), int(bool(y_bf16)), _ptr(stats), _ptr(rm), _ptr(rv),
+                                   _ptr(nbt), float(mom), _ptr(ws), ws.numel(), _stream()))
+        ctx.save_for_backward(feats, weight, x, y, g, stats)
+        ctx.rulebook = rb
+        ctx.relu = bool(relu)
+        ctx.has = (gamma is not None, beta is not None)
+        ctx.mark_non_differentiable(stats)
+        return y, stats
+
+    @staticmethod
+    def backward(ctx, dy, _dstats):
+        L = _lib.lib()
+        feats, weight, x, y, g, stats = ctx.saved_tensors
+        rb = ctx.rulebook
+        cin, cout = int(weight.shape[-2]), int(weight.shape[-1])
+        k = x.shape[0]
+        dy = dy.contiguous()
+        if dy.dtype not in (torch.float32, torch.bfloat16):
+            dy = dy.float()
+        dx = torch.empty((k, cout), dtype=torch.bfloat16, device=x.device)
+        dg = torch.empty((cout,), dtype=torch.float32, device=x.device) if ctx.has[0] else None
+        db = torch.empty((cout,), dtype=torch.float32, device=x.device) if ctx.has[1] else None
+        ws = _ws(L.lcf_bn_workspace_bytes(k, cout), x.device)
+        check(L.lcf_bn_relu_bwd_ex(_ptr(x), 0, _ptr(y), int(y.dtype == torch.bfloat16), _ptr(dy),
+                                   int(dy.dtype == torch.bfloat16), k, cout, _ptr(g), _ptr(stats),
+                                   int(ctx.relu), _ptr(dx), 1, _ptr(dg), _ptr(db), _ptr(ws),
+                                   ws.numel(), _stream()))
+        din = dw = None
+        if ctx.needs_input_grad[0]:
+            din = conv_forward_b16(dx, weight_image_bf16(weight, transpose=True), rb.in_nbr,
+                                   rb.k_in, rb.kvol, cout, cin, out_bf16=True)
+        if ctx.needs_input_grad[1]:
+            dw = conv_wgrad_b16(feats, dx, rb.in_nbr, rb.kvol, cin, cout).view_as(weight).to(
+                weight.dtype)
+        return din, dw, dg, db, None, None, None, None, None
+
+
+def conv_bn_relu_train(conv, norm, x, relu, y_bf16):
+    """``conv`` (a SparseConvolution whose channels b16_conv_supported) on the SparseConvTensor x
+    with bfloat16 features, then nn.BatchNorm1d ``norm`` in training mode (+ ReLU): the fused bf16
+    training node; updates the running statistics; returns the new feature rows."""
+    rb = conv.get_rulebook(x)
+    run = _bn_running(norm)
+    y, stats = ConvBNReLUTrainFunction.apply(x.features, conv.weight, norm.weight, norm.bias, rb,
+                                             norm.eps, relu, run, y_bf16)
+    if norm.track_running_stats and run is None:
+        with torch.no_grad():
+            k, c = y.shape
+            norm.num_batches_tracked += 1
+            m = norm.momentum
+            if m is None:
+                m = 1.0 / float(norm.num_batches_tracked)
+            norm.running_mean.mul_(1 - m).add_(stats[:c], alpha=m)
+            norm.running_var.mul_(1 - m).add_(stats[c:2 * c], alpha=m * k / max(k - 1, 1))
+    return y, rb
+
+
 # ------------------------------------------------------------------ dense
 
 class DenseFunction(torch.autograd.Function):
@@ -706,12 +833,15 @@ def dense(features, indices, batch_size, shape):
 class DenseNHWCBf16Function(torch.autograd.Function):
     @staticmethod
     def forward(ctx, features, indices, batch_size, shape):
-        x = features.float().contiguous()
+        # bf16 rows (the bf16 training path's last layer) go in as they are
+        b16 = features.dtype == torch.bfloat16
+        x = (features if b16 else features.float()).contiguous()
         k, c = x.shape
         d, h, w = shape
         buf = torch.empty((batch_size, h, w, c * d), dtype=torch.bfloat16, device=x.device)
-        check(_lib.lib().lcf_dense_nhwc_bf16(_ptr(x), _ptr(indices), k, None, c, int(batch_size),
-                                             i3(shape), 1, _ptr(buf), _stream()))
+        check(_lib.lib().lcf_dense_nhwc_bf16_rows(_ptr(x), int(b16), _ptr(indices), k, None, c,
+                                                  int(batch_size), i3(shape), 1, _ptr(buf),
+                                                  _stream()))
         ctx.save_for_backward(indices)
         ctx.meta = (k, c, int(batch_size), list(shape), features.dtype)
         return buf.permute(0, 3, 1, 2)  # [B, C*D, H, W], channels_last strides
@@ -721,9 +851,10 @@ class DenseNHWCBf16Function(torch.autograd.Function):
         (indices,) = ctx.saved_tensors
         k, c, b, shape, dt = ctx.meta
         g = grad.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
-        df = torch.empty((k, c), dtype=torch.float32, device=g.device)
-        check(_lib.lib().lcf_dense_nhwc_bf16_bwd(_ptr(g), _ptr(indices), k, c, b, i3(shape),
-                                                 _ptr(df), _stream()))
+        b16 = dt == torch.bfloat16
+        df = torch.empty((k, c), dtype=torch.bfloat16 if b16 else torch.float32, device=g.device)
+        check(_lib.lib().lcf_dense_nhwc_bf16_bwd_rows(_ptr(g), _ptr(indices), k, c, b, i3(shape),
+                                                      _ptr(df), int(b16), _stream()))
         return df.to(dt), None, None, None
 
 

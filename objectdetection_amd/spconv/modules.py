@@ -47,6 +47,13 @@ class SparseSequential(SparseModule):
     """
     fuse_inference = True
     fuse_training = True
+    # under ops.conv_math("bf16") in training: sparse conv -> BatchNorm1d -> ReLU triples whose
+    # channels the bf16-row kernels support run as ONE autograd node on bf16 rows
+    # (ops.ConvBNReLUTrainFunction); False keeps fp32 rows and the conversion at every gather
+    bf16_rows = True
+    # the consumer of the sequence's output takes bf16 rows (the middle extractor's
+    # dense_nhwc_bf16 hand-over to an RPN under autocast)
+    tail_takes_bf16 = False
 
     def __init__(self, *args, **kwargs):
         super().__init__()
@@ -97,13 +104,42 @@ class SparseSequential(SparseModule):
             j += 1
         return j - i, bn, relu
 
+    def _next_takes_bf16(self, mods, j):
+        """True if the rows produced in front of mods[j] should be stored as bf16: the next module
+        is a sparse conv the bf16-row kernels support and followed by a training BatchNorm1d (it
+        will run as the fused node), or the sequence ends and its consumer takes bf16 rows."""
+        if j >= len(mods):
+            return self.tail_takes_bf16
+        m = mods[j]
+        return (is_sparse_conv(m) and m.ndim == 3 and m.bias is None and not m.conv1x1
+                and ops.b16_conv_supported(m.in_channels, m.out_channels)
+                and j + 1 < len(mods) and isinstance(mods[j + 1], nn.BatchNorm1d)
+                and mods[j + 1].training and mods[j + 1].affine)
+
     def forward(self, input):
         mods = list(self._modules.values())
         fuse = (self.fuse_inference and not torch.is_grad_enabled()
                 and isinstance(input, SparseConvTensor) and input.features.is_cuda)
+        b16 = (self.bf16_rows and self.fuse_training and torch.is_grad_enabled()
+               and ops.get_conv_math() == "bf16" and isinstance(input, SparseConvTensor)
+               and input.features.is_cuda)
         i = 0
         while i < len(mods):
             module = mods[i]
+            if (b16 and isinstance(input, SparseConvTensor)
+                    and input.features.dtype == torch.bfloat16 and input.indices.shape[0] != 0
+                    and self._next_takes_bf16(mods, i)):
+                # fused bf16-row node: conv + BatchNorm1d (+ ReLU)
+                relu = i + 2 < len(mods) and isinstance(mods[i + 2], nn.ReLU)
+                nxt = i + (3 if relu else 2)
+                y, rb = ops.conv_bn_relu_train(module, mods[i + 1], input, relu,
+                                               self._next_takes_bf16(mods, nxt))
+                out = SparseConvTensor(y, rb.out_indices, rb.out_shape, input.batch_size)
+                out.indice_dict = input.indice_dict
+                out.grid = input.grid
+                input = out
+                i = nxt
+                continue
             if fuse and is_sparse_conv(module) and isinstance(input, SparseConvTensor):
                 n, bn, relu = self._fusable(mods, i)
                 if n > 1:
@@ -121,8 +157,12 @@ class SparseSequential(SparseModule):
                             and module.training and torch.is_grad_enabled()
                             and ops.bn_relu_supported(input.features)):
                         relu = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
-                        input.features = ops.bn_relu_train(module, input.features, relu)
-                        i += 2 if relu else 1
+                        nxt = i + (2 if relu else 1)
+                        input.features = ops.bn_relu_train(
+                            module, input.features, relu,
+                            y_bf16=b16 and self._next_takes_bf16(mods, nxt)
+                            and input.features.shape[1] % 8 == 0)
+                        i = nxt
                         continue
                     input.features = module(input.features)
             else:

@@ -806,3 +806,103 @@ def test_planned_forward_is_bit_identical_to_the_table_forward(cuda, math):
             if cap_extra:
                 assert (out[:k] - ref).abs().max() <= 1e-5 * ref.abs().max()
             assert bool((out[k:] == 7.0).all())
+
+
+@pytest.mark.parametrize("cin,cout,subm,batch", [(32, 32, True, 1), (64, 64, True, 2),
+                                                 (32, 64, False, 1), (64, 64, False, 2)])
+def test_bf16_row_kernels_match_oracle(oracle, cuda, cin, cout, subm, batch):
+    """The training kernels on rows STORED as bf16 (lcf_indice_conv_fwd_b16 / _wgrad_b16, called
+    through the C ABI): forward, dgrad (in_nbr + transposed image, bf16 output) and wgrad against
+    the oracle run on the same bf16-rounded operands -- products are then exact in fp32, only the
+    summation order and the final rounding differ -- and within the stated bf16 tolerance of the
+    oracle on the unrounded operands."""
+    from objectdetection_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(100 + cin + cout + batch)
+    parts = []
+    for b in range(batch):
+        c = _frame_coors(oracle, 2 + b, 5000)
+        c[:, 0] = b
+        parts.append(c)
+    coors = np.ascontiguousarray(np.concatenate(parts))
+    shape = [41, 1600, 1408]
+    k = coors.shape[0]
+    x = rng.standard_normal((k, cin)).astype(np.float32)
+    w = (rng.standard_normal((3, 3, 3, cin, cout)) / np.sqrt(27 * cin)).astype(np.float32)
+    if subm:
+        pairs, pn = oracle.rulebook_subm(coors, batch, shape, 3)
+        k_out = k
+    else:
+        oc, pairs, pn, _ = oracle.rulebook_conv(coors, batch, shape, 3, 2, 1)
+        k_out = oc.shape[0]
+    g = rng.standard_normal((k_out, cout)).astype(np.float32)
+    rnd = lambda a: torch.from_numpy(a).bfloat16().float().numpy()
+    xr, wr, gr = rnd(x), rnd(w), rnd(g)
+    ref = oracle.indice_conv_fwd(xr, wr, pairs, pn, k_out)
+    din_ref, dw_ref = oracle.indice_conv_bwd(xr, wr, gr, pairs, pn)
+    ref_full = oracle.indice_conv_fwd(x, w, pairs, pn, k_out)
+    rb = ops.build_rulebook(torch.from_numpy(coors).to(cuda), batch, shape, 3, 2, 1, 1, subm)
+    assert rb.k_out == k_out
+    st = torch.cuda.current_stream().cuda_stream
+    xb = torch.from_numpy(x).to(cuda).bfloat16().contiguous()
+    gb = torch.from_numpy(g).to(cuda).bfloat16().contiguous()
+    wt = torch.from_numpy(w).to(cuda)
+    wimg, wimg_t = ops.weight_image_bf16(wt), ops.weight_image_bf16(wt, transpose=True)
+    out = torch.empty((k_out, cout), device=cuda)
+    assert L.lcf_indice_conv_fwd_b16(xb.data_ptr(), wimg.data_ptr(), rb.out_nbr.data_ptr(), k_out,
+                                     27, cin, cout, out.data_ptr(), 0, st) == 0
+    din = torch.empty((k, cin), dtype=torch.bfloat16, device=cuda)
+    assert L.lcf_indice_conv_fwd_b16(gb.data_ptr(), wimg_t.data_ptr(), rb.in_nbr.data_ptr(), k, 27,
+                                     cout, cin, din.data_ptr(), 1, st) == 0
+    dw = torch.empty((27, cin, cout), device=cuda)
+    assert L.lcf_indice_conv_wgrad_b16(xb.data_ptr(), gb.data_ptr(), rb.in_nbr.data_ptr(), k, 27,
+                                       cin, cout, dw.data_ptr(), st) == 0
+    torch.cuda.synchronize()
+    assert rel_err(out.cpu().numpy(), ref) < 1e-5            # fp32 sums of exact products
+    assert rel_err(out.cpu().numpy(), ref_full) < BF16_RTOL
+    assert rel_err(din.float().cpu().numpy(), din_ref) < 4e-3  # + one bf16 rounding of the result
+    assert rel_err(dw.cpu().numpy().reshape(dw_ref.shape), dw_ref) < 1e-5
+    # every G (rows per wave) cuts the same sums: bit-identical outputs
+    out2 = ops.conv_forward_b16(xb, wimg, rb.out_nbr, k_out, 27, cin, cout)
+    assert torch.equal(out, out2)
+    # unsupported shapes and missing operands are refused
+    assert L.lcf_indice_conv_fwd_b16(xb.data_ptr(), wimg.data_ptr(), rb.out_nbr.data_ptr(), k_out,
+                                     27, 16, cout, out.data_ptr(), 0, st) == -3
+    assert L.lcf_indice_conv_fwd_b16(xb.data_ptr(), wimg.data_ptr(), None, k_out, 27, cin, cout,
+                                     out.data_ptr(), 0, st) == -1
+    assert L.lcf_indice_conv_wgrad_b16(xb.data_ptr(), gb.data_ptr(), rb.in_nbr.data_ptr(), k, 27,
+                                       128, 128, dw.data_ptr(), st) == -3
+
+
+@pytest.mark.parametrize("k,c", [(37, 32), (150001, 64), (3000, 128)])
+def test_bn_relu_bf16_rows_and_in_kernel_running_stats(cuda, k, c):
+    """lcf_bn_relu_fwd_ex / _bwd_ex: y stored as bf16 equals the fp32 kernel's y rounded to
+    nearest even; with bf16 dy in and bf16 dx out the gradients equal the fp32 kernels' on the
+    same (rounded) operands; the forward's own running-statistics update equals nn.BatchNorm1d's."""
+    import copy
+    torch.manual_seed(k + c)
+    bn = torch.nn.BatchNorm1d(c, eps=1e-3, momentum=0.01).to(cuda).train()
+    torch.nn.init.uniform_(bn.weight, 0.5, 1.5)
+    torch.nn.init.normal_(bn.bias, std=0.3)
+    ref = copy.deepcopy(bn)
+    x = (torch.randn(k, c, device=cuda) * 2 + 0.7)
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    ya = ops.bn_relu_train(bn, xa, True, y_bf16=True)
+    yb = ops.bn_relu_train(ref, xb, True)
+    assert ya.dtype == torch.bfloat16 and torch.equal(ya, yb.bfloat16())
+    g = torch.randn(k, c, device=cuda).bfloat16()
+    ya.backward(g)
+    yb.backward(g.float())
+    # (the ReLU mask comes from y: bf16 y > 0 exactly where fp32 y > 0)
+    scale = float(xb.grad.abs().max())
+    assert float((xa.grad - xb.grad).abs().max()) / scale < 1e-6
+    assert torch.allclose(bn.weight.grad, ref.weight.grad, rtol=1e-5, atol=1e-5)
+    assert torch.allclose(bn.bias.grad, ref.bias.grad, rtol=1e-5, atol=1e-5)
+    # running statistics: updated inside the forward kernel, against torch's own module
+    tbn = torch.nn.BatchNorm1d(c, eps=1e-3, momentum=0.01).to(cuda).train()
+    tbn.load_state_dict({k_: v for k_, v in ref.state_dict().items()
+                         if "running" not in k_ and "num_batches" not in k_}, strict=False)
+    tbn(x)
+    assert int(bn.num_batches_tracked) == 1 == int(tbn.num_batches_tracked)
+    assert torch.allclose(bn.running_mean, tbn.running_mean, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(bn.running_var, tbn.running_var, rtol=1e-4, atol=1e-6)
