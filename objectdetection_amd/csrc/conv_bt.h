@@ -32,7 +32,8 @@
 template <int CIN, int COUT, int G, bool OUT_BF16>
 __global__ void __launch_bounds__(256)
 cv_bt_kernel(const __bf16 *__restrict__ feat, const __bf16 *__restrict__ wimg,
-             const int *__restrict__ nbr, int k_out, int kvol, void *__restrict__ out)
+             const int *__restrict__ nbr, int k_out, int kvol, void *__restrict__ out,
+             int tiles_per_xcd)
 {
     constexpr int KS = CIN / 32;           // k-steps of 32 input channels
     constexpr int NT = COUT / 16;          // 16-column tiles
@@ -49,7 +50,13 @@ cv_bt_kernel(const __bf16 *__restrict__ feat, const __bf16 *__restrict__ wimg,
     const int wave = tid >> 6;
     const int r16 = lane & 15;
     const int q = lane >> 4;
-    const int row0 = blockIdx.x * ROWS;
+    // Workgroups go round-robin to the 8 XCDs (id % 8), each with its own 4 MB L2.  XCD x takes
+    // the x-th contiguous eighth of the tiles, so that one L2 serves one neighbourhood of rows (at
+    // batch 8: about one frame) instead of every L2 seeing rows from everywhere; tiles_per_xcd = 0
+    // keeps tile = id.
+    const int tile = tiles_per_xcd ? (int)(blockIdx.x & 7) * tiles_per_xcd + (int)(blockIdx.x >> 3)
+                                   : (int)blockIdx.x;
+    const int row0 = tile * ROWS;
     if (row0 >= k_out) return;
 
     // the workgroup's rows of the neighbour table: one contiguous run of ints
@@ -59,7 +66,6 @@ cv_bt_kernel(const __bf16 *__restrict__ feat, const __bf16 *__restrict__ wimg,
         for (int e = tid; e < ROWS * kvol; e += 256) nl[e] = e < live ? src[e] : -1;
     }
     const uint4 *wg = reinterpret_cast<const uint4 *>(wimg);
-    uint4 wreg[WPT];
 #pragma unroll
     for (int x = 0; x < WPT; ++x) {
         const int e = tid + x * 256;
@@ -77,9 +83,11 @@ cv_bt_kernel(const __bf16 *__restrict__ feat, const __bf16 *__restrict__ wimg,
         uint4 v[G][KS];
         int idx[G];
     };
-    // rows of offset o for this lane's G rows
-    auto aload = [&](int o) -> AReg {
-        AReg a;
+    // Rows of offset o for this lane's G rows.  The loads are issued UNCONDITIONALLY (a row
+    // without a neighbour reads row 0, which every such lane shares, and is zeroed when used):
+    // a load behind a branch would make every later s_waitcnt assume the worst, and the point of
+    // this loop is that the next offset's rows stay in flight across the barrier.
+    auto aload = [&](int o, AReg &a) {
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             const int idx = nl[((wave * G + g) * 16 + r16) * kvol + o];
@@ -87,24 +95,21 @@ cv_bt_kernel(const __bf16 *__restrict__ feat, const __bf16 *__restrict__ wimg,
             const uint4 *src =
                 reinterpret_cast<const uint4 *>(feat + (size_t)(idx < 0 ? 0 : idx) * CIN) + q;
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                uint4 v = make_uint4(0u, 0u, 0u, 0u);
-                if (idx >= 0) v = src[ks * 4];
-                a.v[g][ks] = v;
-            }
+            for (int ks = 0; ks < KS; ++ks) a.v[g][ks] = src[ks * 4];
         }
-        return a;
     };
     auto step = [&](int o, const AReg &cur, AReg &next) {
-        const bool more = o + 1 < kvol; // uniform
-        if (more) {
-#pragma unroll
-            for (int x = 0; x < WPT; ++x) {
-                const int e = tid + x * 256;
-                if (WV % 256 == 0 || e < WV) wreg[x] = wg[(size_t)(o + 1) * WV + e];
-            }
-            next = aload(o + 1);
-        }
+        const int on = o + 1 < kvol ? o + 1 : o; // (the last step reloads its own: harmless)
+        // (named registers, not an array: the array form was left in scratch memory, and a
+        // scratch load drains vmcnt like any other)
+        static_assert(WPT <= 4, "W[o] of at most 128 x 64");
+        const uint4 *wsrc = wg + (size_t)on * WV + tid;
+        uint4 w0 = make_uint4(0, 0, 0, 0), w1 = w0, w2 = w0, w3 = w0;
+        if (WV >= 256 || tid < WV) w0 = wsrc[0];
+        if constexpr (WPT > 1) w1 = wsrc[256];
+        if constexpr (WPT > 2) w2 = wsrc[512];
+        if constexpr (WPT > 3) w3 = wsrc[768];
+        aload(on, next);
         // this offset's W fragments: [tg][ks][q][r16] pieces of 8 bf16
         const uint4 *wb = wl + (o & 1) * WV;
         uint4 wf[NT][KS];
@@ -114,32 +119,38 @@ cv_bt_kernel(const __bf16 *__restrict__ feat, const __bf16 *__restrict__ wimg,
             for (int ks = 0; ks < KS; ++ks) wf[t][ks] = wb[((t * KS + ks) * 4 + q) * 16 + r16];
 #pragma unroll
         for (int g = 0; g < G; ++g) {
-            if (__ballot(cur.idx[g] >= 0) == 0ull) continue; // no row of the group has a pair here
+            const bool has = cur.idx[g] >= 0;
+            if (__ballot(has) == 0ull) continue; // no row of the group has a pair here
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                const bf16x8 av = __builtin_bit_cast(bf16x8, cur.v[g][ks]);
+                uint4 u = cur.v[g][ks];
+                u.x = has ? u.x : 0u; u.y = has ? u.y : 0u;
+                u.z = has ? u.z : 0u; u.w = has ? u.w : 0u;
+                const bf16x8 av = __builtin_bit_cast(bf16x8, u);
 #pragma unroll
                 for (int t = 0; t < NT; ++t)
                     acc[g][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                         av, __builtin_bit_cast(bf16x8, wf[t][ks]), acc[g][t], 0, 0, 0);
             }
         }
-        if (more) {
-            uint4 *wn = wl + ((o + 1) & 1) * WV;
-#pragma unroll
-            for (int x = 0; x < WPT; ++x) {
-                const int e = tid + x * 256;
-                if (WV % 256 == 0 || e < WV) wn[e] = wreg[x];
-            }
-        }
-        __syncthreads();
+        uint4 *wn = wl + ((o + 1) & 1) * WV + tid;
+        if (WV >= 256 || tid < WV) wn[0] = w0;
+        if constexpr (WPT > 1) wn[256] = w1;
+        if constexpr (WPT > 2) wn[512] = w2;
+        if constexpr (WPT > 3) wn[768] = w3;
+        // LDS writes done, then the barrier -- NOT __syncthreads(), whose fence also drains
+        // vmcnt(0), i.e. would wait for the rows just requested for the next offset
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     };
 
-    AReg a0 = aload(0), a1;
-    for (int o = 0; o < kvol; o += 2) { // row registers alternate between a0 and a1
+    AReg a0, a1;
+    aload(0, a0);
+    int o = 0;
+    for (; o + 1 < kvol; o += 2) { // row registers alternate between a0 and a1
         step(o, a0, a1);
-        if (o + 1 < kvol) step(o + 1, a1, a0);
+        step(o + 1, a1, a0);
     }
+    if (o < kvol) step(o, a0, a1);
 
     // ---- epilogue: lane (col r16, q) holds rows 4q .. 4q+3 of each 16 x 16 tile
 #pragma unroll
@@ -189,13 +200,16 @@ static int cv_launch_bt_g(const void *feat, const void *wimg, const int *nbr, in
                           void *out, int out_bf16, hipStream_t st)
 {
     const size_t lds = bt_lds_bytes(CIN, COUT, G, kvol);
-    const unsigned grid = (unsigned)((k_out + 64 * G - 1) / (64 * G));
+    const int tiles = (k_out + 64 * G - 1) / (64 * G);
+    static const bool xcd_off = getenv("LCF_BT_XCD") && atoi(getenv("LCF_BT_XCD")) == 0;
+    const int per = xcd_off ? 0 : (tiles + 7) / 8;
+    const unsigned grid = (unsigned)(per ? 8 * per : tiles);
     if (out_bf16)
         cv_bt_kernel<CIN, COUT, G, true><<<grid, 256, lds, st>>>(
-            (const __bf16 *)feat, (const __bf16 *)wimg, nbr, k_out, kvol, out);
+            (const __bf16 *)feat, (const __bf16 *)wimg, nbr, k_out, kvol, out, per);
     else
         cv_bt_kernel<CIN, COUT, G, false><<<grid, 256, lds, st>>>(
-            (const __bf16 *)feat, (const __bf16 *)wimg, nbr, k_out, kvol, out);
+            (const __bf16 *)feat, (const __bf16 *)wimg, nbr, k_out, kvol, out, per);
     LCF_CHECK_LAUNCH();
     return LCF_OK;
 }
@@ -204,10 +218,14 @@ template <int CIN, int COUT>
 static int cv_launch_bt(const void *feat, const void *wimg, const int *nbr, int k_out, int kvol,
                         void *out, int out_bf16, hipStream_t st)
 {
-    // groups per wave: LCF_BT_GROUPS (environment, A/B) or 2
+    // groups per wave: LCF_BT_GROUPS (environment, A/B), else 3 at 64 -> 64 channels and 2
+    // elsewhere (tools/bench_bt.py at batch 8, us for G = 1 / 2 / 3 / 4: 64 -> 64 at 275k rows
+    // 132 / 119 / 112 / 126, at 136k rows 71 / 68 / 64 / -, 32 -> 32 at 348k rows - / 54 / 57 / 60:
+    // more rows per wave amortise the W[o] fragment reads, fewer waves per SIMD hide less)
     static const int genv = getenv("LCF_BT_GROUPS") ? atoi(getenv("LCF_BT_GROUPS")) : 0;
-    const int g = genv ? genv : 2;
+    const int g = genv ? genv : (CIN == 64 && COUT == 64 ? 3 : 2);
     if (g == 1) return cv_launch_bt_g<CIN, COUT, 1>(feat, wimg, nbr, k_out, kvol, out, out_bf16, st);
+    if (g == 3) return cv_launch_bt_g<CIN, COUT, 3>(feat, wimg, nbr, k_out, kvol, out, out_bf16, st);
     if (g == 4) return cv_launch_bt_g<CIN, COUT, 4>(feat, wimg, nbr, k_out, kvol, out, out_bf16, st);
     return cv_launch_bt_g<CIN, COUT, 2>(feat, wimg, nbr, k_out, kvol, out, out_bf16, st);
 }
@@ -232,7 +250,6 @@ extern "C" int lcf_indice_conv_fwd_b16(const void *feat_bf16, const void *wimg_b
     BT_CASE(64, 64);
     BT_CASE(64, 128);
     BT_CASE(128, 64);
-    BT_CASE(128, 128);
 #undef BT_CASE
     return LCF_ERR_UNSUPPORTED;
 }
