@@ -401,7 +401,9 @@ int lcf_indice_conv_wgrad_bf16(const float *feat, const float *dout, const int *
  * when the activations a conv gathers have been written as bf16 by their producer
  * (lcf_bn_relu_fwd_ex / _bwd_ex): gathered rows are 128 bytes at 64 channels, operands go to
  * v_mfma_f32_16x16x32_bf16 without conversion, accumulation is fp32.
- * fwd_b16: feat [k_in,cin] bf16, wimg = lcf_weight_image_bf16, nbr [k_out,kvol]; out [k_out,cout]
+ * fwd_b16: feat [k_in,cin] bf16 (k_in * cin * 2 < 2 GB: the gathers are range-checked buffer
+ *   loads, a missing neighbour reads as zeros without touching memory; every entry of nbr must be
+ *   < k_in), wimg = lcf_weight_image_bf16, nbr [k_out,kvol]; out [k_out,cout]
  *   fp32 (out_bf16 = 0) or bf16 rounded to nearest even (1).  dgrad: the same call over in_nbr
  *   with the transposed image and cin / cout exchanged.  cin, cout in {32, 64, 128}.  No BatchNorm
  *   epilogue (training BatchNorm needs the batch statistics of `out` first).  Deterministic.
@@ -409,9 +411,9 @@ int lcf_indice_conv_wgrad_bf16(const float *feat, const float *dout, const int *
  *   [kvol,cin,cout] fp32 (zeroed inside; fp32 atomics across workgroups); cin, cout in {32, 64}.
  * Stated tolerance of the bf16 forms: 2e-2 of the result's max magnitude against the fp32
  * oracle (operands carry 8 significand bits); measured in tests/test_gpu_conv.py. */
-int lcf_indice_conv_fwd_b16(const void *feat_bf16, const void *wimg_bf16, const int *nbr,
-                            int k_out, int kvol, int cin, int cout, void *out, int out_bf16,
-                            void *stream);
+int lcf_indice_conv_fwd_b16(const void *feat_bf16, int k_in, const void *wimg_bf16,
+                            const int *nbr, int k_out, int kvol, int cin, int cout, void *out,
+                            int out_bf16, void *stream);
 int lcf_indice_conv_wgrad_b16(const void *feat_bf16, const void *dout_bf16, const int *in_nbr,
                               int k_in, int kvol, int cin, int cout, float *dw, void *stream);
 

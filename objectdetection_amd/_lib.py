@@ -117,8 +117,8 @@ SYMBOLS = {
     "lcf_linear_wgrad": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "lcf_indice_conv_wgrad_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                            c_int, c_int, c_void_p, c_void_p]),
-    "lcf_indice_conv_fwd_b16": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
-                                        c_void_p, c_int, c_void_p]),
+    "lcf_indice_conv_fwd_b16": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int,
+                                        c_int, c_void_p, c_int, c_void_p]),
     "lcf_indice_conv_wgrad_b16": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                           c_int, c_void_p, c_void_p]),
     "lcf_dense_nhwc_bf16_rows": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int,

@@ -33,7 +33,7 @@ template <int CIN, int COUT, int G, bool OUT_BF16>
 __global__ void __launch_bounds__(256)
 cv_bt_kernel(const __bf16 *__restrict__ feat, const __bf16 *__restrict__ wimg,
              const int *__restrict__ nbr, int k_out, int kvol, void *__restrict__ out,
-             int tiles_per_xcd)
+             int tiles_per_xcd, unsigned feat_bytes)
 {
     constexpr int KS = CIN / 32;           // k-steps of 32 input channels
     constexpr int NT = COUT / 16;          // 16-column tiles
@@ -83,33 +83,64 @@ cv_bt_kernel(const __bf16 *__restrict__ feat, const __bf16 *__restrict__ wimg,
         uint4 v[G][KS];
         int idx[G];
     };
-    // Rows of offset o for this lane's G rows.  The loads are issued UNCONDITIONALLY (a row
-    // without a neighbour reads row 0, which every such lane shares, and is zeroed when used):
-    // a load behind a branch would make every later s_waitcnt assume the worst, and the point of
-    // this loop is that the next offset's rows stay in flight across the barrier.
+    // Rows of offset o for this lane's G rows: buffer loads through a descriptor of the feature
+    // matrix.  A row without a neighbour takes an offset beyond the descriptor's range: the range
+    // check returns zeros and the lane costs the texture addresser nothing -- with plain loads of a
+    // dummy row for those lanes (53 % of them on a submanifold rulebook) the kernel sat at the
+    // per-CU gather rate (~30 B/clk/CU counting the dummies; tools/bench_bt.py, LCF_BT_LDS_PAD).
+    // Every load is issued unconditionally (no branch around it): a load behind a branch would
+    // make every later s_waitcnt assume the worst, and the point of this loop is that the next
+    // offset's rows stay in flight across the barrier.
+    const __amdgpu_buffer_rsrc_t frs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<__bf16 *>(feat), 0, feat_bytes, 0x00020000);
+    typedef unsigned bt_u4 __attribute__((ext_vector_type(4)));
     auto aload = [&](int o, AReg &a) {
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             const int idx = nl[((wave * G + g) * 16 + r16) * kvol + o];
             a.idx[g] = idx;
-            const uint4 *src =
-                reinterpret_cast<const uint4 *>(feat + (size_t)(idx < 0 ? 0 : idx) * CIN) + q;
+#if defined(BT_ABLATE) && BT_ABLATE == 2 // timing ablation: every gather hits one cached row
+            const int voff = (idx & 63) * (CIN * 2) + q * 16;
+#else
+            const int voff = idx < 0 ? (int)0x80000000 : idx * (CIN * 2) + q * 16;
+#endif
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) a.v[g][ks] = src[ks * 4];
+            for (int ks = 0; ks < KS; ++ks) {
+                const bt_u4 w = __builtin_amdgcn_raw_buffer_load_b128(frs, voff + ks * 64, 0, 0);
+                a.v[g][ks] = make_uint4(w.x, w.y, w.z, w.w);
+            }
         }
     };
-    auto step = [&](int o, const AReg &cur, AReg &next) {
-        const int on = o + 1 < kvol ? o + 1 : o; // (the last step reloads its own: harmless)
-        // (named registers, not an array: the array form was left in scratch memory, and a
-        // scratch load drains vmcnt like any other)
-        static_assert(WPT <= 4, "W[o] of at most 128 x 64");
-        const uint4 *wsrc = wg + (size_t)on * WV + tid;
-        uint4 w0 = make_uint4(0, 0, 0, 0), w1 = w0, w2 = w0, w3 = w0;
+    // W[o] travels global -> registers -> LDS one step AHEAD of the rows: step o stores W[o+1]
+    // (requested during step o-1, so its L2 round trip had a whole step to land) and requests
+    // W[o+2] into the same registers.  (Named registers, not an array: the array form was left in
+    // scratch memory, and a scratch load drains vmcnt like any other.)
+    static_assert(WPT <= 4, "W[o] of at most 128 x 64");
+    uint4 w0 = make_uint4(0, 0, 0, 0), w1 = w0, w2 = w0, w3 = w0;
+    auto wload = [&](int o) {
+#if defined(BT_ABLATE) && BT_ABLATE == 3 // timing ablation: workgroups read different W[o] at a time
+        const uint4 *wsrc = wg + (size_t)(((o < kvol ? o : kvol - 1) + blockIdx.x) % kvol) * WV + tid;
+#elif defined(BT_ABLATE) && BT_ABLATE == 4 // timing ablation: no W traffic after the first two
+        const uint4 *wsrc = wg + (size_t)(o & 1) * WV + tid;
+#else
+        const uint4 *wsrc = wg + (size_t)(o < kvol ? o : kvol - 1) * WV + tid;
+#endif
         if (WV >= 256 || tid < WV) w0 = wsrc[0];
         if constexpr (WPT > 1) w1 = wsrc[256];
         if constexpr (WPT > 2) w2 = wsrc[512];
         if constexpr (WPT > 3) w3 = wsrc[768];
-        aload(on, next);
+    };
+    auto wstore = [&](int o) {
+        uint4 *wn = wl + (o & 1) * WV + tid;
+        if (WV >= 256 || tid < WV) wn[0] = w0;
+        if constexpr (WPT > 1) wn[256] = w1;
+        if constexpr (WPT > 2) wn[512] = w2;
+        if constexpr (WPT > 3) wn[768] = w3;
+    };
+    auto step = [&](int o, const AReg &cur, AReg &next) {
+        wstore(o + 1); // W[o+1] -> the buffer W[o-1] was read from (everyone is past that barrier)
+        wload(o + 2);
+        aload(o + 1 < kvol ? o + 1 : o, next); // (the last step reloads its own: harmless)
         // this offset's W fragments: [tg][ks][q][r16] pieces of 8 bf16
         const uint4 *wb = wl + (o & 1) * WV;
         uint4 wf[NT][KS];
@@ -123,27 +154,27 @@ cv_bt_kernel(const __bf16 *__restrict__ feat, const __bf16 *__restrict__ wimg,
             if (__ballot(has) == 0ull) continue; // no row of the group has a pair here
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                uint4 u = cur.v[g][ks];
-                u.x = has ? u.x : 0u; u.y = has ? u.y : 0u;
-                u.z = has ? u.z : 0u; u.w = has ? u.w : 0u;
-                const bf16x8 av = __builtin_bit_cast(bf16x8, u);
+                const bf16x8 av = __builtin_bit_cast(bf16x8, cur.v[g][ks]);
+#if defined(BT_ABLATE) && BT_ABLATE == 1 // timing ablation: one MFMA per k-step instead of NT
+                acc[g][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                    av, __builtin_bit_cast(bf16x8, wf[ks % NT][ks]), acc[g][0], 0, 0, 0);
+#pragma unroll
+                for (int t = 1; t < NT; ++t) acc[g][t][0] += __uint_as_float(wf[t][ks].x);
+#else
 #pragma unroll
                 for (int t = 0; t < NT; ++t)
                     acc[g][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                         av, __builtin_bit_cast(bf16x8, wf[t][ks]), acc[g][t], 0, 0, 0);
+#endif
             }
         }
-        uint4 *wn = wl + ((o + 1) & 1) * WV + tid;
-        if (WV >= 256 || tid < WV) wn[0] = w0;
-        if constexpr (WPT > 1) wn[256] = w1;
-        if constexpr (WPT > 2) wn[512] = w2;
-        if constexpr (WPT > 3) wn[768] = w3;
-        // LDS writes done, then the barrier -- NOT __syncthreads(), whose fence also drains
-        // vmcnt(0), i.e. would wait for the rows just requested for the next offset
+        // LDS accesses done, then the barrier -- NOT __syncthreads(), whose fence also drains
+        // vmcnt(0), i.e. would wait for the rows and the W[o+2] just requested
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     };
 
     AReg a0, a1;
+    wload(1);
     aload(0, a0);
     int o = 0;
     for (; o + 1 < kvol; o += 2) { // row registers alternate between a0 and a1
@@ -197,26 +228,28 @@ static size_t bt_lds_bytes(int cin, int cout, int g, int kvol)
 
 template <int CIN, int COUT, int G>
 static int cv_launch_bt_g(const void *feat, const void *wimg, const int *nbr, int k_out, int kvol,
-                          void *out, int out_bf16, hipStream_t st)
+                          void *out, int out_bf16, unsigned feat_bytes, hipStream_t st)
 {
-    const size_t lds = bt_lds_bytes(CIN, COUT, G, kvol);
+    // LCF_BT_LDS_PAD (environment, diagnosis): extra LDS bytes per workgroup, to cap how many share a CU
+    static const size_t pad = getenv("LCF_BT_LDS_PAD") ? (size_t)atoi(getenv("LCF_BT_LDS_PAD")) : 0;
+    const size_t lds = bt_lds_bytes(CIN, COUT, G, kvol) + pad;
     const int tiles = (k_out + 64 * G - 1) / (64 * G);
     static const bool xcd_off = getenv("LCF_BT_XCD") && atoi(getenv("LCF_BT_XCD")) == 0;
     const int per = xcd_off ? 0 : (tiles + 7) / 8;
     const unsigned grid = (unsigned)(per ? 8 * per : tiles);
     if (out_bf16)
         cv_bt_kernel<CIN, COUT, G, true><<<grid, 256, lds, st>>>(
-            (const __bf16 *)feat, (const __bf16 *)wimg, nbr, k_out, kvol, out, per);
+            (const __bf16 *)feat, (const __bf16 *)wimg, nbr, k_out, kvol, out, per, feat_bytes);
     else
         cv_bt_kernel<CIN, COUT, G, false><<<grid, 256, lds, st>>>(
-            (const __bf16 *)feat, (const __bf16 *)wimg, nbr, k_out, kvol, out, per);
+            (const __bf16 *)feat, (const __bf16 *)wimg, nbr, k_out, kvol, out, per, feat_bytes);
     LCF_CHECK_LAUNCH();
     return LCF_OK;
 }
 
 template <int CIN, int COUT>
 static int cv_launch_bt(const void *feat, const void *wimg, const int *nbr, int k_out, int kvol,
-                        void *out, int out_bf16, hipStream_t st)
+                        void *out, int out_bf16, unsigned feat_bytes, hipStream_t st)
 {
     // groups per wave: LCF_BT_GROUPS (environment, A/B), else 3 at 64 -> 64 channels and 2
     // elsewhere (tools/bench_bt.py at batch 8, us for G = 1 / 2 / 3 / 4: 64 -> 64 at 275k rows
@@ -224,16 +257,21 @@ static int cv_launch_bt(const void *feat, const void *wimg, const int *nbr, int 
     // more rows per wave amortise the W[o] fragment reads, fewer waves per SIMD hide less)
     static const int genv = getenv("LCF_BT_GROUPS") ? atoi(getenv("LCF_BT_GROUPS")) : 0;
     const int g = genv ? genv : (CIN == 64 && COUT == 64 ? 3 : 2);
-    if (g == 1) return cv_launch_bt_g<CIN, COUT, 1>(feat, wimg, nbr, k_out, kvol, out, out_bf16, st);
-    if (g == 3) return cv_launch_bt_g<CIN, COUT, 3>(feat, wimg, nbr, k_out, kvol, out, out_bf16, st);
-    if (g == 4) return cv_launch_bt_g<CIN, COUT, 4>(feat, wimg, nbr, k_out, kvol, out, out_bf16, st);
-    return cv_launch_bt_g<CIN, COUT, 2>(feat, wimg, nbr, k_out, kvol, out, out_bf16, st);
+    if (g == 1) return cv_launch_bt_g<CIN, COUT, 1>(feat, wimg, nbr, k_out, kvol, out, out_bf16, feat_bytes, st);
+    if (g == 3) return cv_launch_bt_g<CIN, COUT, 3>(feat, wimg, nbr, k_out, kvol, out, out_bf16, feat_bytes, st);
+    if (g == 4) return cv_launch_bt_g<CIN, COUT, 4>(feat, wimg, nbr, k_out, kvol, out, out_bf16, feat_bytes, st);
+    return cv_launch_bt_g<CIN, COUT, 2>(feat, wimg, nbr, k_out, kvol, out, out_bf16, feat_bytes, st);
 }
 
-extern "C" int lcf_indice_conv_fwd_b16(const void *feat_bf16, const void *wimg_bf16,
+extern "C" int lcf_indice_conv_fwd_b16(const void *feat_bf16, int k_in, const void *wimg_bf16,
                                        const int *nbr, int k_out, int kvol, int cin, int cout,
                                        void *out, int out_bf16, void *stream)
 {
+    // (k_in: rows of feat -- the gathers go through a range-checked buffer descriptor of
+    // k_in * cin * 2 bytes, which must stay below 2 GB)
+    if (k_in < 0 || (unsigned long long)k_in * (unsigned)cin * 2ull >= 0x80000000ull)
+        return LCF_ERR_RANGE;
+    const unsigned feat_bytes = (unsigned)k_in * (unsigned)cin * 2u;
     if (k_out < 0 || kvol <= 0 || kvol > LCF_MAX_KVOL || !wimg_bf16 || !nbr || !out ||
         (k_out > 0 && !feat_bf16))
         return LCF_ERR_ARG;
@@ -243,7 +281,7 @@ extern "C" int lcf_indice_conv_fwd_b16(const void *feat_bf16, const void *wimg_b
     hipStream_t st = (hipStream_t)stream;
 #define BT_CASE(A, B) \
     if (cin == A && cout == B) \
-        return cv_launch_bt<A, B>(feat_bf16, wimg_bf16, nbr, k_out, kvol, out, out_bf16, st)
+        return cv_launch_bt<A, B>(feat_bf16, wimg_bf16, nbr, k_out, kvol, out, out_bf16, feat_bytes, st)
     BT_CASE(32, 32);
     BT_CASE(32, 64);
     BT_CASE(64, 32);

@@ -684,7 +684,7 @@ def conv_forward_b16(features, wimg, nbr, n_rows, kvol, cin, cout, out_bf16=Fals
     x = features.contiguous()
     out = torch.empty((int(n_rows), int(cout)),
                       dtype=torch.bfloat16 if out_bf16 else torch.float32, device=x.device)
-    check(_lib.lib().lcf_indice_conv_fwd_b16(_ptr(x), _ptr(wimg), _ptr(nbr), int(n_rows),
+    check(_lib.lib().lcf_indice_conv_fwd_b16(_ptr(x), x.shape[0], _ptr(wimg), _ptr(nbr), int(n_rows),
                                              int(kvol), int(cin), int(cout), _ptr(out),
                                              int(bool(out_bf16)), _stream()))
     return out

@@ -849,11 +849,12 @@ def test_bf16_row_kernels_match_oracle(oracle, cuda, cin, cout, subm, batch):
     wt = torch.from_numpy(w).to(cuda)
     wimg, wimg_t = ops.weight_image_bf16(wt), ops.weight_image_bf16(wt, transpose=True)
     out = torch.empty((k_out, cout), device=cuda)
-    assert L.lcf_indice_conv_fwd_b16(xb.data_ptr(), wimg.data_ptr(), rb.out_nbr.data_ptr(), k_out,
-                                     27, cin, cout, out.data_ptr(), 0, st) == 0
+    assert L.lcf_indice_conv_fwd_b16(xb.data_ptr(), k, wimg.data_ptr(), rb.out_nbr.data_ptr(),
+                                     k_out, 27, cin, cout, out.data_ptr(), 0, st) == 0
     din = torch.empty((k, cin), dtype=torch.bfloat16, device=cuda)
-    assert L.lcf_indice_conv_fwd_b16(gb.data_ptr(), wimg_t.data_ptr(), rb.in_nbr.data_ptr(), k, 27,
-                                     cout, cin, din.data_ptr(), 1, st) == 0
+    assert L.lcf_indice_conv_fwd_b16(gb.data_ptr(), k_out, wimg_t.data_ptr(),
+                                     rb.in_nbr.data_ptr(), k, 27, cout, cin, din.data_ptr(), 1,
+                                     st) == 0
     dw = torch.empty((27, cin, cout), device=cuda)
     assert L.lcf_indice_conv_wgrad_b16(xb.data_ptr(), gb.data_ptr(), rb.in_nbr.data_ptr(), k, 27,
                                        cin, cout, dw.data_ptr(), st) == 0
@@ -866,9 +867,9 @@ def test_bf16_row_kernels_match_oracle(oracle, cuda, cin, cout, subm, batch):
     out2 = ops.conv_forward_b16(xb, wimg, rb.out_nbr, k_out, 27, cin, cout)
     assert torch.equal(out, out2)
     # unsupported shapes and missing operands are refused
-    assert L.lcf_indice_conv_fwd_b16(xb.data_ptr(), wimg.data_ptr(), rb.out_nbr.data_ptr(), k_out,
-                                     27, 16, cout, out.data_ptr(), 0, st) == -3
-    assert L.lcf_indice_conv_fwd_b16(xb.data_ptr(), wimg.data_ptr(), None, k_out, 27, cin, cout,
+    assert L.lcf_indice_conv_fwd_b16(xb.data_ptr(), k, wimg.data_ptr(), rb.out_nbr.data_ptr(),
+                                     k_out, 27, 16, cout, out.data_ptr(), 0, st) == -3
+    assert L.lcf_indice_conv_fwd_b16(xb.data_ptr(), k, wimg.data_ptr(), None, k_out, 27, cin, cout,
                                      out.data_ptr(), 0, st) == -1
     assert L.lcf_indice_conv_wgrad_b16(xb.data_ptr(), gb.data_ptr(), rb.in_nbr.data_ptr(), k, 27,
                                        128, 128, dw.data_ptr(), st) == -3
