@@ -35,14 +35,15 @@ HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md "HBM3E peak BW" (spec)
 
 
 def dominant_kernel_roofline(model, clouds, math="f32", reps=20):
-    """Times every launch of the dominant kernel -- the 3x3x3, 64->64 channel indice_conv (fused
-    gather-GEMM-scatter + BN + ReLU): cv_q4_kernel<64,64,4>, fp32 MFMA over tile plans as
-    FrameEngine launches it (math "f32"; 7 launches per frame), or cv_tc_kernel<64,64,32> with
-    bf16 MFMA operands over neighbour tables as the training step launches it (math "bf16") --
-    with HIP events on the stream it is launched on,
-    after the timed region.  achieved = algorithmic flops per launch (2 * pairs * Cin * Cout,
-    SURVEY.md section 8d) / average launch duration; the same launches priced in algorithmic
-    bytes (K_in*Cin*4 + K_out*Cout*4 + K_out*kvol*4 + kvol*Cin*Cout*e) against HBM."""
+    """Times every launch of the dominant kernel -- the 64->64 channel indice_conv:
+    cv_q4_kernel<64,64,4>, fp32 MFMA over tile plans (fused gather-GEMM-scatter + BN + ReLU) as
+    FrameEngine launches it (math "f32"; the 7 3x3x3 launches of a frame), or cv_bt_kernel<64,64,3>
+    on rows stored as bf16 as the training step launches it for forward and dgrad (math "bf16";
+    the 8 forward launches of a batch, the 3-offset one included) -- with HIP events on the stream
+    it is launched on, after the timed region.  achieved = algorithmic flops per launch
+    (2 * pairs * Cin * Cout) / average launch duration; the same launches
+    priced in algorithmic bytes (K_in*Cin*e_in + K_out*Cout*4 + K_out*kvol*4 + kvol*Cin*Cout*e_w;
+    e = 4 for fp32 rows / weights, 2 for bf16) against HBM."""
     from objectdetection_amd.spconv import SparseConvTensor
     from objectdetection_amd.spconv.modules import _bn_affine
     mid = model.middle_feature_extractor
@@ -67,9 +68,13 @@ def dominant_kernel_roofline(model, clouds, math="f32", reps=20):
                         (x.features, conv._weight_image(), plan, tr, rb.k_out, rb.kvol, 64, 64,
                          scale, shift, True))
             else:
-                call = (ops.conv_forward_bf16,
-                        (x.features, ops.weight_image_bf16(conv.weight), rb.out_nbr, rb.k_out,
-                         rb.kvol, 64, 64, scale, shift, True))
+                # the training step's forward / dgrad kernel: rows stored as bf16, fp32 out, no
+                # epilogue (training BatchNorm needs the batch statistics first)
+                nbytes = rb.k_in * 64 * 2 + rb.k_out * 64 * 4 + rb.k_out * rb.kvol * 4 + \
+                    rb.kvol * 64 * 64 * 2
+                call = (ops.conv_forward_b16,
+                        (x.features.bfloat16(), ops.weight_image_bf16(conv.weight), rb.out_nbr,
+                         rb.k_out, rb.kvol, 64, 64))
             launches.append((call, pairs, nbytes))
         x = conv(x, _scale=scale, _shift=shift, _relu=True)
         i += 3
@@ -100,7 +105,7 @@ def dominant_kernel_roofline(model, clouds, math="f32", reps=20):
         except (OSError, KeyError, ValueError):
             pass
     common = {"kernel": "cv_q4_kernel<64,64,4>" if math == "f32" else
-              "cv_tc_kernel<64,64,32> (bf16 operands)",
+              "cv_bt_kernel<64,64,3> (bf16 rows, fp32 accumulate and output)",
               "launches_per_frame" if math == "f32" else "launches_timed": n,
               "avg_launch_us": round(avg_s * 1e6, 2),
               "flops_per_launch": round(total_flops / n, 0),
@@ -237,7 +242,7 @@ def train_measurement(args, dev, rank, world, dist, barrier):
         el = float(t.item())
     nparams = sum(p.numel() for p in step.net.parameters())
     roof = None
-    if rank == 0:  # the step's dominant kernel on one of its batches (profiles/r02_train_*)
+    if rank == 0:  # the step's dominant kernel on one of its batches (profiles/r03*_train_*)
         with torch.no_grad():
             step.net.eval()
             roof = dominant_kernel_roofline(step.net.frontend, batches[0], math="bf16", reps=10)
@@ -247,9 +252,9 @@ def train_measurement(args, dev, rank, world, dist, barrier):
             "value": round(world * b * args.train_steps / el, 2), "unit": "frames/s",
             "ms_per_step": round(el / args.train_steps * 1e3, 2), "steps": args.train_steps,
             "global_batch": world * b, "scaling": "weak",
-            "dtype": "bf16 MFMA indice_conv fwd/dgrad (fp32 accumulate; wgrad at fp32 tolerance: "
-                     "fp32 MFMA, split hi+lo bf16 operands on the wide layers; fp32 master "
-                     "weights), bf16 autocast RPN",
+            "dtype": "bf16 MFMA indice_conv fwd/dgrad/wgrad on bf16-stored rows at 32/64 channels "
+                     "(fp32 accumulate, fp32 conv outputs and BatchNorm statistics, fp32 master "
+                     "weights; the 16-channel level-0 layers fp32 MFMA), bf16 autocast RPN",
             "allreduce_bytes": 4 * nparams if world > 1 else 0,
             "loss": round(float(loss), 4)}
 
