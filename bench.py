@@ -140,8 +140,9 @@ def cpu_baseline(model_name, cloud_np, budget_s, max_voxels=40000):
     return {"value": round(fps, 3), "unit": "frames/s", "cores": threads, "kind": "port",
             "host_cpus": os.cpu_count(),
             "sample": f"{iters} timed passes of the same N={cloud_np.shape[0]} frame (seed 0) "
-                      f"through oracle/cpu_pipeline.py after 1 warm-up; median "
-                      f"{np.median(times) * 1e3:.0f} ms/frame; restatement of numba "
+                      f"through oracle/cpu_pipeline.py after up to 5 warm-ups; median "
+                      f"{np.median(times) * 1e3:.0f} ms/frame, p10 {np.percentile(times, 10) * 1e3:.0f}, "
+                      f"p90 {np.percentile(times, 90) * 1e3:.0f}; restatement of numba "
                       f"points_to_voxel (1 thread) + spconv CPU indice_conv (torch.mm, "
                       f"{threads} threads), not the original binaries"}
 
@@ -218,6 +219,115 @@ def light_curtain_measurement(dev, cloud_np, with_cpu, reps=30):
     return out
 
 
+def _murmur32(k):
+    """lcf_hash32 (csrc/common.h) on an int64 tensor of 32-bit keys."""
+    m = 0xFFFFFFFF
+    h = k & m
+    h = h ^ (h >> 16)
+    h = (h * 0x85ebca6b) & m
+    h = h ^ (h >> 13)
+    h = (h * 0xc2b2ae35) & m
+    return h ^ (h >> 16)
+
+
+def _pow2_capacity(items):
+    need, p = max(2 * int(items), 1024), 1
+    while p < need:
+        p <<= 1
+    return p
+
+
+def hash_table_stats(ws, capacity, wide):
+    """Occupancy and probe lengths of one of liblcf's open-addressing tables as the kernels left it
+    (read from the workspace, off the timed path): `ws` the uint8 workspace whose first bytes are
+    the table -- 32-bit keys (voxelizer, submanifold level) or 64-bit key << 32 | stamp entries
+    (strided levels) --, linear probing from lcf_hash32(key) & (capacity - 1).  A resident key's
+    probe count = its displacement from the home slot + 1 = what a successful look-up of it walks
+    (and at least what its insert walked)."""
+    if wide:
+        t = ws[:capacity * 8].view(torch.int64)
+        occ = t != -1
+        key = (t >> 32) & 0xFFFFFFFF
+    else:
+        t = ws[:capacity * 4].view(torch.int32)
+        occ = t != -1
+        key = t.long() & 0xFFFFFFFF
+    slot = torch.nonzero(occ).flatten()
+    if slot.numel() == 0:
+        return {"slots": capacity, "load_factor": 0.0, "probes_mean": 0.0, "probes_max": 0}
+    disp = (slot - _murmur32(key[slot])) & (capacity - 1)
+    return {"slots": capacity, "load_factor": round(slot.numel() / capacity, 4),
+            "probes_mean": round(float((disp + 1).float().mean()), 3),
+            "probes_max": int(disp.max()) + 1}
+
+
+def dense_lc_measurement(dev, model_name, steps=60):
+    """BASELINE.json configs[4] at one GPU: a dense light-curtain-augmented, SYNTHIA-shaped frame
+    (120,000 points, 640x480, 39.32 deg FOV, 10 curtains; second/data/synthia_dataset.py:53-55)
+    through the same FrameEngine path (max_voxels 160000), with the rows of every level and --
+    the configuration exists to stress them -- the occupancy and probe lengths of the coordinate
+    hash tables ("report hash-table load factor and probe counts")."""
+    import ctypes
+    from objectdetection_amd import _lib
+    from objectdetection_amd._lib import f3, f6
+    n, mv = 120000, 160000
+    model = randomize_(SparseFrontEnd(model_name, max_voxels=mv).eval(), 0).to(dev)
+    clouds = [torch.from_numpy(synth.synthia_frame(i, n)).to(dev) for i in range(4)]
+    calib = [torch.from_numpy(synth.synthia_frame(100000 + i, n)).to(dev) for i in range(2)]
+    with torch.no_grad():
+        eng = model.engine(calib=calib)
+        for i in range(10):
+            eng.forward(clouds[i % 4])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            eng.forward(clouds[i % 4])
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        eng.check()
+        rows = eng.counts()
+        # hash tables of that last frame, rebuilt off the timed path by calls that leave them in
+        # place (the engine re-arms its own behind every frame): the voxelizer's with the caller's
+        # sizing (2 slots per point), the chain's with the engine's calibrated capacities
+        L = _lib.lib()
+        st = torch.cuda.current_stream().cuda_stream
+        pts = clouds[(steps - 1) % 4]
+        ws = torch.empty(L.lcf_voxelize_workspace_bytes(n, 5), dtype=torch.uint8, device=dev)
+        v = torch.empty((mv, 5, 4), device=dev)
+        c = torch.empty((mv, 4), dtype=torch.int32, device=dev)
+        num = torch.empty(mv, dtype=torch.int32, device=dev)
+        k = torch.zeros(1, dtype=torch.int32, device=dev)
+        _lib.check(L.lcf_voxelize(pts.data_ptr(), n, None, 4, f3(synth.VOXEL_SIZE),
+                                  f6(synth.PC_RANGE), 5, mv, 0, 0, 4, v.data_ptr(), c.data_ptr(),
+                                  num.data_ptr(), k.data_ptr(), ws.data_ptr(), ws.numel(), st))
+        tables = {"voxelizer": hash_table_stats(ws, _pow2_capacity(n), False)}
+        chain = eng.chain
+        chain.run(c, k_dev=k)  # no WS_CLEAN context: resets its own tables first, leaves them built
+        torch.cuda.synchronize()
+        tables["submanifold level 0"] = hash_table_stats(chain.ws0, _pow2_capacity(chain.k_cap),
+                                                         False)
+        cap = chain.k_cap
+        for i in chain.strided:
+            lv = chain.levels[i]
+            E = 1
+            for d in range(3):
+                E *= (lv.ksize[d] + lv.stride[d] - 1) // lv.stride[d]
+            tables[f"strided level {chain.strided.index(i) + 1}"] = hash_table_stats(
+                chain.ws[i], _pow2_capacity(min(cap * E, lv.cap_out)), True)
+            cap = lv.cap_out
+        eng._reset_workspaces(st)
+    return {"workload": "one 120000-point SYNTHIA-shaped frame per step (10 curtains), "
+                        "max_voxels 160000, FrameEngine, batch 1 (BASELINE.json configs[4] at one "
+                        "GPU)",
+            "value": round(steps / el, 2), "unit": "frames/s",
+            "ms_per_step": round(el / steps * 1e3, 4), "steps": steps,
+            "rows_per_level": rows, "level_capacities": eng.level_caps,
+            "hash_tables": tables,
+            "note": "tables: open addressing, linear probing, capacity = pow2 >= 2 x items "
+                    "(strided levels: items = the level's row capacity, 2.0 x the calibrated "
+                    "count); probes = slots a look-up of a resident key walks"}
+
+
 def train_measurement(args, dev, rank, world, dist, barrier):
     """BASELINE.json configs[2]/[3]: training step (VFE + sparse middle fwd/dgrad/wgrad + RPNV2 +
     loss + optimizer) on `train_batch` frames per rank, scene-sharded, ONE flat gradient
@@ -225,9 +335,23 @@ def train_measurement(args, dev, rank, world, dist, barrier):
     from objectdetection_amd.train import TrainStep
     step = TrainStep(dev, args.model, seed=0)
     b = args.train_batch
-    frames = [torch.from_numpy(synth.vkitti_frame(1000 + rank * 2 * b + i, args.points)).to(dev)
-              for i in range(2 * b)]
-    batches = [frames[:b], frames[b:]]
+    # Two global batches of b x world scenes.  One rank: b frames of args.points points each
+    # (BASELINE.json configs[2]).  Several ranks (configs[3]): scenes of MIXED sizes (0.6 .. 1.4 x
+    # args.points, the same list on every rank) dealt to the ranks by cost with dist.shard_scenes
+    # -- K varies per frame, so equal frame counts are not equal work;
+    # a rank generates only its own shard.
+    from objectdetection_amd.dist import shard_scenes
+    batches, shard_info = [], []
+    for bi in range(2):
+        rng = np.random.default_rng(7 + bi)
+        sizes = [args.points] * (b * world) if world == 1 else \
+            [int(args.points * f) for f in rng.uniform(0.6, 1.4, b * world)]
+        shards = shard_scenes(sizes, world)
+        batches.append([torch.from_numpy(synth.vkitti_frame(1000 + bi * b * world + i,
+                                                            sizes[i])).to(dev)
+                        for i in shards[rank]])
+        shard_info.append({"frames_per_rank": [len(sh) for sh in shards],
+                           "points_per_rank": [sum(sizes[i] for i in sh) for sh in shards]})
     for i in range(6):  # MIOpen times its solvers for the RPN on the first steps
         step(batches[i % 2])
     barrier()
@@ -251,7 +375,7 @@ def train_measurement(args, dev, rank, world, dist, barrier):
             "metric": "frames/s training step (VFE + sparse middle fwd/dgrad/wgrad + RPNV2)",
             "value": round(world * b * args.train_steps / el, 2), "unit": "frames/s",
             "ms_per_step": round(el / args.train_steps * 1e3, 2), "steps": args.train_steps,
-            "global_batch": world * b, "scaling": "weak",
+            "global_batch": world * b, "scaling": "weak", "scene_shards": shard_info,
             "dtype": "bf16 MFMA indice_conv fwd/dgrad/wgrad on bf16-stored rows at 32/64 channels "
                      "(fp32 accumulate, fp32 conv outputs and BatchNorm statistics, fp32 master "
                      "weights; the 16-channel level-0 layers fp32 MFMA), bf16 autocast RPN",
@@ -493,6 +617,8 @@ def main(argv=None):
         if world == 1 and not args.eager and not args.no_alt:
             line["light_curtain"] = light_curtain_measurement(dev, clouds_np[0],
                                                               not args.no_cpu_baseline)
+            if args.model != "M3" and args.shape == "vkitti":
+                line["dense_lc"] = dense_lc_measurement(dev, args.model)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.model, clouds_np[0], args.cpu_budget,
                                                 args.max_voxels)

@@ -92,9 +92,15 @@ def frontend_forward(model_cpu, clouds):
     return d.reshape(d.shape[0], d.shape[1] * d.shape[2], d.shape[3], d.shape[4])
 
 
-def time_frontend(model_cpu, clouds, budget_s=20.0, min_iters=2, max_iters=30):
-    """-> (frames/s, iterations, threads).  One untimed warm-up, then iterate until the budget."""
-    frontend_forward(model_cpu, clouds)
+def time_frontend(model_cpu, clouds, budget_s=20.0, min_iters=2, max_iters=30, warmups=5):
+    """-> (frames/s from the median, iterations, threads, times).  SURVEY.md section 8d's
+    protocol: 5 untimed warm-ups, then up to 30 timed passes (fewer only when the budget runs
+    out first); the caller reports median and p10 / p90."""
+    t_w = time.perf_counter()
+    for i in range(warmups):
+        frontend_forward(model_cpu, clouds)
+        if i >= 1 and time.perf_counter() - t_w > 0.4 * budget_s:
+            break  # a slow host: keep most of the budget for timed passes
     times = []
     t_end = time.perf_counter() + budget_s
     while len(times) < max_iters and (len(times) < min_iters or time.perf_counter() < t_end):

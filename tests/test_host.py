@@ -222,6 +222,95 @@ def test_reference_files_import_unmodified_on_the_dropin():
     assert isinstance(blk, spconv.SparseModule)
 
 
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree not present")
+def test_reference_voxelnet_builds_on_the_dropin():
+    """second/pytorch/models/voxelnet.py -- the caller SURVEY.md section 8 a15 says must keep
+    working -- loaded UNMODIFIED on the drop-in in the build container, and VoxelNet constructed
+    with the shipped configuration (SimpleVoxel / VoxelFeatureExtractor + SpMiddleFHD + RPNV2,
+    second/configs/vkitti/second/base.yaml:5-35): the front-end modules network_forward calls
+    (voxelnet.py:314-337) are the reference's own classes over OUR spconv / VoxelGeneratorV2, and
+    the state_dict carries the reference's keys.  Absent third-party packages (numba, torchvision:
+    only ResNetRPN needs it) are empty stand-ins; no forward runs here (no GPU in this container,
+    and the reference tree does not travel to the GPU box)."""
+    import contextlib
+    import objectdetection_amd.dropin as dropin
+    collections.Iterable = collections.abc.Iterable
+    nb = sys.modules.get("numba") or types.ModuleType("numba")
+
+    def _jit(*a, **k):
+        if len(a) == 1 and callable(a[0]) and not k:
+            return a[0]
+        return lambda f: f
+    nb.jit = nb.njit = _jit
+    nb.prange = range
+    cu = types.ModuleType("numba.cuda")
+    cu.jit = _jit
+    nb.cuda = cu
+    sys.modules["numba"], sys.modules["numba.cuda"] = nb, cu
+    if "torchvision" not in sys.modules:
+        tv, tvm = types.ModuleType("torchvision"), types.ModuleType("torchvision.models")
+        tvm.resnet = types.ModuleType("torchvision.models.resnet")
+        tv.models = tvm
+        sys.modules.update({"torchvision": tv, "torchvision.models": tvm,
+                            "torchvision.models.resnet": tvm.resnet})
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    dropin.install()
+    import spconv
+    for name in ("second.pytorch", "second.pytorch.models"):
+        if name not in sys.modules:
+            mod = types.ModuleType(name)
+            mod.__path__ = [os.path.join(REF, *name.split("."))]
+            sys.modules[name] = mod
+    utils = types.ModuleType("second.pytorch.utils")
+    utils.torch_timer = lambda *a, **k: contextlib.nullcontext()
+    sys.modules["second.pytorch.utils"] = utils
+
+    def load(name, rel):
+        spec = importlib.util.spec_from_file_location(name, os.path.join(REF, rel))
+        mod = importlib.util.module_from_spec(spec)
+        sys.modules[name] = mod
+        spec.loader.exec_module(mod)
+        setattr(sys.modules[name.rsplit(".", 1)[0]], name.rsplit(".", 1)[1], mod)
+        return mod
+
+    for n in ("resnet", "middle", "voxel_encoder", "pointpillars", "rpn"):
+        load("second.pytorch.models." + n, f"second/pytorch/models/{n}.py")
+    vn = load("second.pytorch.models.voxelnet", "second/pytorch/models/voxelnet.py")
+
+    from spconv.utils import VoxelGeneratorV2
+    gen = VoxelGeneratorV2([0.05, 0.05, 0.1], [0, -40, -3, 70.4, 40, 1], 5, 40000)
+    grid = gen.grid_size  # second_builder.py:30-31
+    dense_shape = [1] + grid[::-1].tolist() + [16]
+    assert dense_shape == [1, 40, 1600, 1408, 16]
+    coder = types.SimpleNamespace(code_size=7)
+    assigner = types.SimpleNamespace(box_coder=coder, num_anchors_per_location=2)
+    for vfe_name, vfe_out in (("SimpleVoxel", 4), ("VoxelFeatureExtractor", 128)):
+        net = vn.VoxelNet(dense_shape, num_class=1, num_input_features=4,
+                          vfe_class_name=vfe_name, vfe_num_filters=[32, 128],
+                          middle_class_name="SpMiddleFHD", middle_num_input_features=vfe_out,
+                          rpn_class_name="RPNV2", rpn_num_input_features=128,
+                          rpn_layer_nums=[5], rpn_layer_strides=[1], rpn_num_filters=[128],
+                          rpn_upsample_strides=[1], rpn_num_upsample_filters=[128],
+                          target_assigner=assigner, voxel_generator=gen)
+        ref_models = sys.modules["second.pytorch.models.middle"]
+        assert type(net.middle_feature_extractor) is ref_models.SpMiddleFHD
+        assert isinstance(net.middle_feature_extractor.middle_conv, spconv.SparseSequential)
+        convs = [m for m in net.middle_feature_extractor.middle_conv
+                 if isinstance(m, (spconv.SubMConv3d, spconv.SparseConv3d))]
+        assert len(convs) == 14 and net.voxel_generator is gen
+        keys = set(net.state_dict())
+        assert {"middle_feature_extractor.middle_conv.0.weight", "rpn.conv_cls.weight",
+                "global_step"} <= keys
+        w = net.state_dict()["middle_feature_extractor.middle_conv.0.weight"]
+        assert tuple(w.shape) == (3, 3, 3, vfe_out, 16)  # spconv 1.x layout [kD,kH,kW,Cin,Cout]
+        # our own extractor loads the reference module's weights key for key
+        from objectdetection_amd import middle as our_middle
+        ours = our_middle.SpMiddleFHD(dense_shape, use_norm=True, num_input_features=vfe_out)
+        ours.load_state_dict(net.middle_feature_extractor.state_dict(), strict=True)
+        assert callable(net.network_forward)
+
+
 def test_rpn_and_engine_surface():
     """RPNV2 (downstream consumer of the training-step measurement) has the reference's shapes,
     state_dict keys and parameter count; FrameEngine refuses to run without a GPU."""
