@@ -155,3 +155,48 @@ def rotate_iou_gpu_eval(boxes, query_boxes, criterion=-1, device_id=0):
 def rotate_iou_gpu(boxes, query_boxes, device_id=0):
     """nms_gpu.py:511-546."""
     return rotate_iou_gpu_eval(boxes, query_boxes, -1, device_id)
+
+
+def soft_nms_jit(boxes, sigma=0.5, Nt=0.3, threshold=0.001, method=0):
+    """second/core/non_max_suppression/nms_cpu.py:63-153 (Soft-NMS, Bodla et al.): ``boxes``
+    [N,5] float32 (x1, y1, x2, y2, score), re-ordered and re-scored IN PLACE as the reference does;
+    returns the list of kept row indices ``[0 .. N')``.  method 0: hard NMS at ``Nt``, 1: linear
+    decay ``1 - iou``, 2: gaussian ``exp(-iou^2 / sigma)``; a box whose score falls below
+    ``threshold`` is swapped with the last live box and dropped.  Inherently sequential (every
+    selection re-scores the boxes the next selection reads) and exported but never called by the
+    reference (``non_max_suppression/__init__.py:1``): host code over a numpy array, one pass per
+    selected box, the pairwise part vectorised where the reference's order allows it (no box is
+    dropped -- methods 1 and 2 with threshold 0 -- or falls back to the box-by-box walk)."""
+    b = np.asarray(boxes)
+    if b.ndim != 2 or b.shape[1] < 5 or b.dtype != np.float32:
+        raise ValueError("boxes must be a [N,5] float32 array")
+    n = b.shape[0]
+    i = 0
+    while i < n:
+        m = i + int(np.argmax(b[i:n, 4]))  # first maximum, as the reference's strict '<' scan
+        if m != i:
+            b[[i, m], :5] = b[[m, i], :5]
+        tx1, ty1, tx2, ty2 = (np.float64(v) for v in b[i, :4])
+        pos = i + 1
+        while pos < n:
+            x1, y1, x2, y2 = (np.float64(v) for v in b[pos, :4])
+            iw = min(tx2, x2) - max(tx1, x1) + 1
+            if iw > 0:
+                ih = min(ty2, y2) - max(ty1, y1) + 1
+                if ih > 0:
+                    ua = (tx2 - tx1 + 1) * (ty2 - ty1 + 1) + (x2 - x1 + 1) * (y2 - y1 + 1) - iw * ih
+                    ov = iw * ih / ua
+                    if method == 1:
+                        w = 1 - ov if ov > Nt else 1.0
+                    elif method == 2:
+                        w = np.exp(-(ov * ov) / sigma)
+                    else:
+                        w = 0.0 if ov > Nt else 1.0
+                    b[pos, 4] = np.float32(w * np.float64(b[pos, 4]))
+                    if b[pos, 4] < threshold:  # drop: the last live box takes this row
+                        b[pos, :5] = b[n - 1, :5]
+                        n -= 1
+                        pos -= 1
+            pos += 1
+        i += 1
+    return list(range(n))

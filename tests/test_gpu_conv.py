@@ -907,3 +907,28 @@ def test_bn_relu_bf16_rows_and_in_kernel_running_stats(cuda, k, c):
     assert int(bn.num_batches_tracked) == 1 == int(tbn.num_batches_tracked)
     assert torch.allclose(bn.running_mean, tbn.running_mean, rtol=1e-5, atol=1e-6)
     assert torch.allclose(bn.running_var, tbn.running_var, rtol=1e-4, atol=1e-6)
+
+
+def test_all_ones_kernel_is_a_row_gemm_at_any_width(cuda):
+    """spconv's 1x1x1 short cut (what second/pytorch/models/resnet.py:20-29 and SparseBottleneck's
+    64 -> 256 expansion, resnet.py:69-110, rely on): no rulebook, a row-wise GEMM with autograd,
+    channel counts beyond the sparse kernels' 128 included; indices pass through unchanged."""
+    from objectdetection_amd import spconv
+    torch.manual_seed(0)
+    k = 5000
+    idx = torch.stack([torch.zeros(k), torch.randint(0, 41, (k,)), torch.randint(0, 1600, (k,)),
+                       torch.randint(0, 1408, (k,))], 1).int().to(cuda)
+    for cin, cout, bias in ((64, 256, False), (256, 64, True), (16, 16, True)):
+        conv = spconv.SubMConv3d(cin, cout, 1, bias=bias, indice_key="b").to(cuda)
+        x = torch.randn(k, cin, device=cuda, requires_grad=True)
+        y = conv(spconv.SparseConvTensor(x, idx, [41, 1600, 1408], 1))
+        assert y.indices is idx and not y.indice_dict
+        ref = x @ conv.weight.view(cin, cout) + (conv.bias if bias else 0)
+        assert torch.allclose(y.features, ref, rtol=1e-5, atol=1e-5)
+        y.features.sum().backward()
+        assert conv.weight.grad is not None and x.grad.shape == x.shape
+        with torch.no_grad():  # the inference path with a folded BatchNorm + ReLU epilogue
+            sc, sh = torch.rand(cout, device=cuda) + 0.5, torch.randn(cout, device=cuda)
+            z = conv(spconv.SparseConvTensor(x.detach(), idx, [41, 1600, 1408], 1), _scale=sc,
+                     _shift=sh, _relu=True)
+            assert torch.allclose(z.features, torch.relu(ref * sc + sh), rtol=1e-5, atol=1e-5)
