@@ -634,7 +634,8 @@ int lcf_voxelize_append(const float *points, int n_capacity, int n_begin, int n_
  *   camera-x index xi = Y-1-y, camera-z index zi = x.
  * lcf_lc_dp_design replaces DPOptimizedPolicy.get_design_points (policy.py:283-434) given the
  *   cached graph (policy.py:160-281, built on the host from the device geometry): node_k [T,N]
- *   i32 = index of every ray point into ulookup, theta_las [T,N] f64 = its laser angle in degrees,
+ *   i32 = index of every ray point into ulookup [n_lookup] (an index outside the table -- a
+ *   graph built for another map shape -- reads entry 0, "outside the map"), theta_las [T,N] f64 = its laser angle in degrees,
  *   max_dtheta = laser_vel_limit * laser_timestep; choice [T] i32 = the point chosen on each
  *   ray t (rays in the graph's order; the reference returns their (x, z) flipped).  Value
  *   functions in float32 (uncertainty) and float64 (laser cost) as numpy computes them: the
@@ -644,9 +645,9 @@ int lcf_lc_entropy_lookup(const float *cls, int K, int Y, int X,
                           const unsigned char *anchors_mask, int apply_sigmoid, float *ulookup,
                           void *stream);
 size_t lcf_lc_dp_workspace_bytes(int T, int N);
-int lcf_lc_dp_design(const float *ulookup, const int *node_k, const double *theta_las, int T,
-                     int N, double max_dtheta, int *choice, void *ws, size_t ws_bytes,
-                     void *stream);
+int lcf_lc_dp_design(const float *ulookup, int n_lookup, const int *node_k,
+                     const double *theta_las, int T, int N, double max_dtheta, int *choice,
+                     void *ws, size_t ws_bytes, void *stream);
 
 #ifdef __cplusplus
 }

@@ -167,7 +167,7 @@ SYMBOLS = {
     "lcf_lc_entropy_lookup": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p,
                                       c_void_p]),
     "lcf_lc_dp_workspace_bytes": (c_size_t, [c_int, c_int]),
-    "lcf_lc_dp_design": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, ctypes.c_double,
+    "lcf_lc_dp_design": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, ctypes.c_double,
                                  c_void_p, c_void_p, c_size_t, c_void_p]),
     "lcf_bn_workspace_bytes": (c_size_t, [c_int, c_int]),
     "lcf_bn_relu_fwd": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, ctypes.c_float, c_int,

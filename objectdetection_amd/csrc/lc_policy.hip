@@ -68,13 +68,17 @@ __device__ __forceinline__ MinIdx lcp_min(MinIdx a, MinIdx b)
 //   angles are monotonic along a ray, so it is); (1 | 0 << 8) = "no window" otherwise (no allowed
 //   successor, or a set with holes): the walk then scans all N successors with the test.
 __global__ void __launch_bounds__(256)
-lc_prepare_kernel(const float *__restrict__ ulookup, const int *__restrict__ node_k,
+lc_prepare_kernel(const float *__restrict__ ulookup, int n_lookup,
+                  const int *__restrict__ node_k,
                   const double *__restrict__ theta_las, int T, int N, double max_dtheta,
                   float *__restrict__ r_unc, unsigned short *__restrict__ win)
 {
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= T * N) return;
-    r_unc[e] = ulookup[node_k[e]];
+    // (a graph built for another map shape must not read beyond the table: an index outside it
+    // counts as "outside the map", entry 0, whose value is 0)
+    const int k = node_k[e];
+    r_unc[e] = ulookup[(unsigned)k < (unsigned)n_lookup ? k : 0];
     const int t = e / N;
     unsigned short w = 1;
     if (t < T - 1) {
@@ -373,11 +377,11 @@ static size_t lcp_lds_bytes(int N) // without the next_idx bytes
     return (size_t)(2 * LCP_CHUNK * N + 2 * N) * (8 + 4) + (size_t)2 * LCP_CHUNK * N * 2;
 }
 
-extern "C" int lcf_lc_dp_design(const float *ulookup, const int *node_k, const double *theta_las,
-                                int T, int N, double max_dtheta, int *choice, void *ws,
-                                size_t ws_bytes, void *stream)
+extern "C" int lcf_lc_dp_design(const float *ulookup, int n_lookup, const int *node_k,
+                                const double *theta_las, int T, int N, double max_dtheta,
+                                int *choice, void *ws, size_t ws_bytes, void *stream)
 {
-    if (!ulookup || !node_k || !theta_las || !choice || !ws || T <= 0 || N <= 0)
+    if (!ulookup || n_lookup <= 0 || !node_k || !theta_las || !choice || !ws || T <= 0 || N <= 0)
         return LCF_ERR_ARG;
     if (N > LCP_MAXN) return LCF_ERR_UNSUPPORTED;
     if ((long long)T * N >= (1ll << 29)) return LCF_ERR_RANGE;
@@ -411,7 +415,7 @@ extern "C" int lcf_lc_dp_design(const float *ulookup, const int *node_k, const d
     }
     const int n = T * N;
     lc_prepare_kernel<<<(n + 255) / 256, 256, 0, (hipStream_t)stream>>>(
-        ulookup, node_k, theta_las, T, N, max_dtheta, r_unc, win);
+        ulookup, n_lookup, node_k, theta_las, T, N, max_dtheta, r_unc, win);
     LCF_CHECK_LAUNCH();
     kern<<<1, LCP_THREADS, lds, (hipStream_t)stream>>>(
         r_unc, win, theta_las, T, N, max_dtheta, nx_in_lds, next_idx, choice, vu, vl);

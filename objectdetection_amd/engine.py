@@ -116,6 +116,8 @@ class FrameEngine:
         self.max_points = int(max_points)
         self.graph = None
         self.level_caps = None
+        # weight images and folded BatchNorm: once (they do not depend on the capacities)
+        self._fold()
         # plan with worst-case-ish capacities, measure, then re-plan tight and capture
         self._plan(None)
         self.level_need = None  # rows per level seen in calibration (kernel-selection hint)
@@ -209,7 +211,6 @@ class FrameEngine:
         i32, f32 = torch.int32, torch.float32
         MV, T, F = self.max_voxels, self.T, self.F
         E = lambda *s, dtype=f32: torch.empty(s, dtype=dtype, device=dev)
-        self._fold()
         self.points = E(self.max_points, F)
         self.n_dev = torch.zeros(1, dtype=i32, device=dev)
         self.voxels, self.coors = E(MV, T, F), E(MV, 4, dtype=i32)
@@ -708,9 +709,12 @@ class FrameBatch:
             raise ValueError("FrameBatch owns the output buffer")
         p = next(model.parameters(), None)
         dev = p.device if p is not None else torch.device("cuda", torch.cuda.current_device())
-        probe = FrameEngine(model, use_graph=False)  # uncalibrated, uncaptured: for the shape
-        _, C, D, H, W = probe.dense.shape
-        del probe
+        # the dense shape from the layer list alone (no buffers planned, no weights folded)
+        probe = FrameEngine.__new__(FrameEngine)
+        mid = model.middle_feature_extractor
+        probe.sparse_shape = [int(x) for x in mid.sparse_shape]
+        probe._parse_middle(list(mid.middle_conv))
+        C, (D, H, W) = probe.layers[-1].cout, probe.out_shape
         self.dense = torch.empty((batch, C, D, H, W), dtype=torch.float32, device=dev)
         self.out = self.dense.view(batch, C * D, H, W)
         self.engines = [FrameEngine(model, calib=calib, dense_out=self.dense[b:b + 1], **engine_kw)

@@ -239,7 +239,8 @@ class DPOptimizedPolicy(Policy):
         T, n = g["node_k"].shape
         assert ulookup.numel() == 1 + g["umap_wh"][0] * g["umap_wh"][1]
         check(_lib.lib().lcf_lc_dp_design(
-            ulookup.data_ptr(), g["node_k"].data_ptr(), g["theta_las_dev"].data_ptr(), T, n,
+            ulookup.data_ptr(), ulookup.numel(), g["node_k"].data_ptr(),
+            g["theta_las_dev"].data_ptr(), T, n,
             float(self._max_dtheta_las), g["choice"].data_ptr(), g["ws"].data_ptr(),
             g["ws"].numel(), _stream()))
         return g["choice"]

@@ -31,7 +31,7 @@ def _dp(cuda, ul, node_k, theta, max_dtheta):
     ul_d = torch.from_numpy(ul).to(cuda)
     nk = torch.from_numpy(node_k.astype(np.int32)).to(cuda)
     th = torch.from_numpy(np.ascontiguousarray(theta)).to(cuda)
-    _lib.check(L.lcf_lc_dp_design(ul_d.data_ptr(), nk.data_ptr(), th.data_ptr(), T, N,
+    _lib.check(L.lcf_lc_dp_design(ul_d.data_ptr(), ul_d.numel(), nk.data_ptr(), th.data_ptr(), T, N,
                                   float(max_dtheta), choice.data_ptr(), ws.data_ptr(),
                                   ws.numel(), torch.cuda.current_stream().cuda_stream))
     torch.cuda.synchronize()
@@ -131,9 +131,22 @@ def test_dp_rejects_bad_arguments(cuda):
     L = _lib.lib()
     buf = torch.zeros(1 << 16, dtype=torch.uint8, device=cuda)
     p = buf.data_ptr()
-    assert L.lcf_lc_dp_design(p, p, p, 4, 300, 0.2, p, p, buf.numel(), 0) == -3  # LCF_ERR_UNSUPPORTED
-    assert L.lcf_lc_dp_design(p, p, p, 4, 80, 0.2, p, p, 16, 0) == -2  # LCF_ERR_WORKSPACE
-    assert L.lcf_lc_dp_design(0, p, p, 4, 80, 0.2, p, p, buf.numel(), 0) == -1  # LCF_ERR_ARG
+    assert L.lcf_lc_dp_design(p, 9, p, p, 4, 300, 0.2, p, p, buf.numel(), 0) == -3  # LCF_ERR_UNSUPPORTED
+    assert L.lcf_lc_dp_design(p, 9, p, p, 4, 80, 0.2, p, p, 16, 0) == -2  # LCF_ERR_WORKSPACE
+    assert L.lcf_lc_dp_design(0, 9, p, p, 4, 80, 0.2, p, p, buf.numel(), 0) == -1  # LCF_ERR_ARG
+    assert L.lcf_lc_dp_design(p, 0, p, p, 4, 80, 0.2, p, p, buf.numel(), 0) == -1  # empty table
+    # node indices beyond the table (a graph built for another map shape) read entry 0 instead
+    # of memory behind it: all-zero rewards, a finite answer, no fault
+    T, N = 6, 80
+    ul = torch.zeros(5, device=cuda)
+    nk = torch.full((T, N), 10 ** 6, dtype=torch.int32, device=cuda)
+    th = torch.linspace(-20, 20, N, device=cuda, dtype=torch.float64).repeat(T, 1).contiguous()
+    ws = torch.zeros(L.lcf_lc_dp_workspace_bytes(T, N), dtype=torch.uint8, device=cuda)
+    ch = torch.full((T,), -1, dtype=torch.int32, device=cuda)
+    assert L.lcf_lc_dp_design(ul.data_ptr(), 5, nk.data_ptr(), th.data_ptr(), T, N, 0.21,
+                              ch.data_ptr(), ws.data_ptr(), ws.numel(), 0) == 0
+    torch.cuda.synchronize()
+    assert int(ch.min()) >= 0 and int(ch.max()) < N
     assert L.lcf_lc_entropy_lookup(p, 0, 4, 4, 0, 0, p, 0) == -1  # LCF_ERR_ARG
 
 
