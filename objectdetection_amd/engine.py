@@ -572,7 +572,15 @@ class FrameEngine:
 
     def forward(self, points, sync=False):
         """points [N,4] f32 cuda -> [1, C*D, H, W] (the engine's static output buffer: consume or
-        clone it before the next call).  Nothing here waits for the GPU unless sync=True."""
+        clone it before the next call).  Nothing here waits for the GPU unless sync=True.
+
+        FAILURE BEHAVIOUR differs from the spconv-API path, which sizes every level from a host
+        read and cannot overflow: here a frame with more active sites than a level's calibrated
+        capacity (2 x the calibration frames' counts) is TRUNCATED at that level -- rows beyond
+        the capacity are dropped, the returned features are those of the truncated frame -- and
+        only a device flag records it.  Nothing raises unless the caller asks: ``check()`` (one
+        synchronisation, e.g. once per batch of frames) raises, ``overflowed()`` tells, and
+        ``forward(..., sync=True)`` checks every frame and re-plans + re-runs it by itself."""
         self._load(points)
         return self._run(points, sync)
 
