@@ -554,6 +554,15 @@ int lcf_bn_relu_bwd_ex(const void *x, int x_bf16, const void *y, int y_bf16, con
                        int dy_bf16, int k, int c, const float *gamma, const float *stats, int relu,
                        void *dx, int dx_bf16, float *dgamma, float *dbeta, void *ws,
                        size_t ws_bytes, void *stream);
+/* Backward of the pair on ALL-bf16 rows (x, dy, dx bf16; 16 bytes per thread): the form the dense
+ * RPN's BatchNorm2d + ReLU takes on channels_last activations under bf16 autocast (rows = pixels,
+ * second/pytorch/models/rpn.py:467-497 in training; its forward is lcf_bn_relu_fwd_ex with x_bf16
+ * = y_bf16 = 1).  The ReLU mask is the sign of the forward's output RECOMPUTED from x, gamma, beta
+ * and stats with the forward's own fused multiply-add, so y is not read (beta is needed for
+ * that).  c a multiple of 8 and <= 128. */
+int lcf_bn_relu_bwd_b16(const void *x_bf16, const void *dy_bf16, int k, int c, const float *gamma,
+                        const float *beta, const float *stats, int relu, void *dx_bf16,
+                        float *dgamma, float *dbeta, void *ws, size_t ws_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Rotated / axis-aligned IoU and non-maximum suppression (the predict-time

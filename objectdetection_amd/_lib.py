@@ -179,6 +179,9 @@ SYMBOLS = {
     "lcf_bn_relu_bwd_ex": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int,
                                    c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p,
                                    c_void_p, c_void_p, c_size_t, c_void_p]),
+    "lcf_bn_relu_bwd_b16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p,
+                                    c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                    c_size_t, c_void_p]),
     "lcf_bn_relu_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p,
                                 c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
                                 c_void_p]),

@@ -247,6 +247,214 @@ bn_bwd_apply_kernel(const TX *__restrict__ x, const TY *__restrict__ y,
     }
 }
 
+// ---- all-bf16 rows, eight channels (16 bytes) per thread: the dense RPN's BatchNorm2d + ReLU on
+// channels_last activations (rows = pixels, C = 128: 72 MB per tensor at batch 8).  Same
+// partition, partials and finalise as above; the backward takes the ReLU mask from the sign of
+// the recomputed output instead of reading y (one 72 MB read less in each of its two passes).
+struct Bn8 {
+    float v[8];
+};
+
+__device__ __forceinline__ Bn8 bn_ld8(const __bf16 *row, int c8)
+{
+    const uint4 u = reinterpret_cast<const uint4 *>(row)[c8];
+    Bn8 r;
+    r.v[0] = __uint_as_float(u.x << 16); r.v[1] = __uint_as_float(u.x & 0xFFFF0000u);
+    r.v[2] = __uint_as_float(u.y << 16); r.v[3] = __uint_as_float(u.y & 0xFFFF0000u);
+    r.v[4] = __uint_as_float(u.z << 16); r.v[5] = __uint_as_float(u.z & 0xFFFF0000u);
+    r.v[6] = __uint_as_float(u.w << 16); r.v[7] = __uint_as_float(u.w & 0xFFFF0000u);
+    return r;
+}
+
+__device__ __forceinline__ void bn_st8(__bf16 *row, int c8, const Bn8 &r)
+{
+    uint4 u;
+    u.x = lcf_bf16_rne(r.v[0]) | (lcf_bf16_rne(r.v[1]) << 16);
+    u.y = lcf_bf16_rne(r.v[2]) | (lcf_bf16_rne(r.v[3]) << 16);
+    u.z = lcf_bf16_rne(r.v[4]) | (lcf_bf16_rne(r.v[5]) << 16);
+    u.w = lcf_bf16_rne(r.v[6]) | (lcf_bf16_rne(r.v[7]) << 16);
+    reinterpret_cast<uint4 *>(row)[c8] = u;
+}
+
+// thread -> (row lane, group of 8 channels); sums a[8] | b[8] per thread -> part[0:c] | part[c:2c]
+__device__ __forceinline__ void bn8_block_reduce(int c, int c8n, int rl, int c8, int RL,
+                                                 const Bn8 &a, const Bn8 &b, float *lds, float *part)
+{
+    if (rl < RL) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            lds[rl * 2 * c + c8 * 8 + j] = a.v[j];
+            lds[rl * 2 * c + c + c8 * 8 + j] = b.v[j];
+        }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 2 * c; e += BN_BLOCK) {
+        float s = 0.f;
+        for (int r = 0; r < RL; ++r) s += lds[r * 2 * c + e];
+        part[e] = s;
+    }
+}
+
+__global__ void __launch_bounds__(BN_BLOCK)
+bn8_stats_kernel(const __bf16 *__restrict__ x, int k, int c, int rows_per_block,
+                 float *__restrict__ parts)
+{
+    __shared__ __align__(16) float lds[BN_BLOCK * 16];
+    const int c8n = c >> 3, RL = BN_BLOCK / c8n, rl = threadIdx.x / c8n, c8 = threadIdx.x % c8n;
+    const int r0 = blockIdx.x * rows_per_block, r1 = min(k, r0 + rows_per_block);
+    Bn8 s, q;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s.v[j] = q.v[j] = 0.f;
+    if (rl < RL) {
+        for (int r = r0 + rl; r < r1; r += RL) {
+            const Bn8 v = bn_ld8(x + (size_t)r * c, c8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                s.v[j] += v.v[j];
+                q.v[j] += v.v[j] * v.v[j];
+            }
+        }
+    }
+    bn8_block_reduce(c, c8n, rl, c8, RL, s, q, lds, parts + (size_t)blockIdx.x * 2 * c);
+}
+
+__global__ void __launch_bounds__(BN_BLOCK)
+bn8_apply_relu_kernel(const __bf16 *__restrict__ x, int k, int c, int rows_per_block,
+                      const double *__restrict__ sums, const float *__restrict__ gamma,
+                      const float *__restrict__ beta, float eps, int relu,
+                      __bf16 *__restrict__ y, float *__restrict__ stats, BnRunning run)
+{
+    __shared__ __align__(16) float sc[BN_MAX_C], sh[BN_MAX_C];
+    for (int e = threadIdx.x; e < c; e += BN_BLOCK) {
+        const double mean = sums[e] / k;
+        double var = sums[c + e] / k - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float inv = (float)(1.0 / sqrt(var + (double)eps));
+        const float g = gamma ? gamma[e] : 1.f;
+        sc[e] = g * inv;
+        sh[e] = (beta ? beta[e] : 0.f) - (float)mean * g * inv;
+        if (blockIdx.x == 0) {
+            stats[e] = (float)mean;
+            stats[c + e] = (float)var;
+            stats[2 * c + e] = inv;
+            if (run.mean) {
+                const float mo = run.momentum;
+                run.mean[e] = (1.f - mo) * run.mean[e] + mo * (float)mean;
+                run.var[e] = (1.f - mo) * run.var[e] +
+                             mo * (float)(var * ((double)k / (double)(k > 1 ? k - 1 : 1)));
+                if (e == 0 && run.batches) run.batches[0] += 1;
+            }
+        }
+    }
+    __syncthreads();
+    const int c8n = c >> 3, RL = BN_BLOCK / c8n, rl = threadIdx.x / c8n, c8 = threadIdx.x % c8n;
+    if (rl >= RL) return;
+    float a[8], b[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        a[j] = sc[c8 * 8 + j];
+        b[j] = sh[c8 * 8 + j];
+    }
+    const int r0 = blockIdx.x * rows_per_block, r1 = min(k, r0 + rows_per_block);
+    for (int r = r0 + rl; r < r1; r += RL) {
+        Bn8 v = bn_ld8(x + (size_t)r * c, c8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            v.v[j] = __fmaf_rn(v.v[j], a[j], b[j]);
+            if (relu) v.v[j] = fmaxf(v.v[j], 0.f);
+        }
+        bn_st8(y + (size_t)r * c, c8, v);
+    }
+}
+
+// g = dy * (y > 0) with y's sign recomputed as in the forward (same fused multiply-add)
+__global__ void __launch_bounds__(BN_BLOCK)
+bn8_bwd_reduce_kernel(const __bf16 *__restrict__ x, const __bf16 *__restrict__ dy, int k, int c,
+                      int rows_per_block, const float *__restrict__ stats,
+                      const float *__restrict__ gamma, const float *__restrict__ beta, int relu,
+                      float *__restrict__ parts)
+{
+    __shared__ __align__(16) float lds[BN_BLOCK * 16];
+    const int c8n = c >> 3, RL = BN_BLOCK / c8n, rl = threadIdx.x / c8n, c8 = threadIdx.x % c8n;
+    const int r0 = blockIdx.x * rows_per_block, r1 = min(k, r0 + rows_per_block);
+    Bn8 s, q;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s.v[j] = q.v[j] = 0.f;
+    if (rl < RL) {
+        float mean[8], inv[8], a[8], b[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int e = c8 * 8 + j;
+            mean[j] = stats[e];
+            inv[j] = stats[2 * c + e];
+            const float g = gamma ? gamma[e] : 1.f;
+            a[j] = g * inv[j];
+            b[j] = (beta ? beta[e] : 0.f) - mean[j] * g * inv[j];
+        }
+        for (int r = r0 + rl; r < r1; r += RL) {
+            const Bn8 xv = bn_ld8(x + (size_t)r * c, c8);
+            const Bn8 gv = bn_ld8(dy + (size_t)r * c, c8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float g = gv.v[j];
+                if (relu && !(__fmaf_rn(xv.v[j], a[j], b[j]) > 0.f)) g = 0.f;
+                s.v[j] += g;
+                q.v[j] += g * (xv.v[j] - mean[j]) * inv[j];
+            }
+        }
+    }
+    bn8_block_reduce(c, c8n, rl, c8, RL, s, q, lds, parts + (size_t)blockIdx.x * 2 * c);
+}
+
+__global__ void __launch_bounds__(BN_BLOCK)
+bn8_bwd_apply_kernel(const __bf16 *__restrict__ x, const __bf16 *__restrict__ dy, int k, int c,
+                     int rows_per_block, const float *__restrict__ stats,
+                     const double *__restrict__ sums, const float *__restrict__ gamma,
+                     const float *__restrict__ beta, int relu, __bf16 *__restrict__ dx,
+                     float *__restrict__ dgamma, float *__restrict__ dbeta)
+{
+    __shared__ __align__(16) float mg[BN_MAX_C], mgx[BN_MAX_C], gi[BN_MAX_C];
+    for (int e = threadIdx.x; e < c; e += BN_BLOCK) {
+        const double sg = sums[e], sgx = sums[c + e];
+        mg[e] = (float)(sg / k);
+        mgx[e] = (float)(sgx / k);
+        gi[e] = (gamma ? gamma[e] : 1.f) * stats[2 * c + e];
+        if (blockIdx.x == 0) {
+            if (dgamma) dgamma[e] = (float)sgx;
+            if (dbeta) dbeta[e] = (float)sg;
+        }
+    }
+    __syncthreads();
+    const int c8n = c >> 3, RL = BN_BLOCK / c8n, rl = threadIdx.x / c8n, c8 = threadIdx.x % c8n;
+    if (rl >= RL) return;
+    float mean[8], inv[8], a[8], b[8], m1[8], m2[8], w[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int e = c8 * 8 + j;
+        mean[j] = stats[e];
+        inv[j] = stats[2 * c + e];
+        const float g = gamma ? gamma[e] : 1.f;
+        a[j] = g * inv[j];
+        b[j] = (beta ? beta[e] : 0.f) - mean[j] * g * inv[j];
+        m1[j] = mg[e];
+        m2[j] = mgx[e];
+        w[j] = gi[e];
+    }
+    const int r0 = blockIdx.x * rows_per_block, r1 = min(k, r0 + rows_per_block);
+    for (int r = r0 + rl; r < r1; r += RL) {
+        const Bn8 xv = bn_ld8(x + (size_t)r * c, c8);
+        const Bn8 gv = bn_ld8(dy + (size_t)r * c, c8);
+        Bn8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float g = gv.v[j];
+            if (relu && !(__fmaf_rn(xv.v[j], a[j], b[j]) > 0.f)) g = 0.f;
+            o.v[j] = w[j] * (g - m1[j] - (xv.v[j] - mean[j]) * inv[j] * m2[j]);
+        }
+        bn_st8(dx + (size_t)r * c, c8, o);
+    }
+}
+
 // rows per block / number of partials for k rows: enough blocks to fill the chip, at most
 // BN_MAX_PARTS partials
 static void bn_partition(int k, int *rows_per_block, int *nparts)
@@ -289,6 +497,16 @@ static int bn_fwd_run(const void *x, int x_bf16, int k, int c, const float *gamm
     hipStream_t st = (hipStream_t)stream;
     float *parts = (float *)ws;
     double *sums = (double *)((char *)ws + (size_t)BN_MAX_PARTS * 2 * c * sizeof(float));
+    if (x_bf16 && y_bf16) { // all-bf16 rows: the 16-byte-per-thread kernels
+        bn8_stats_kernel<<<np, BN_BLOCK, 0, st>>>((const __bf16 *)x, k, c, rpb, parts);
+        LCF_CHECK_LAUNCH();
+        bn_finalize_kernel<<<2 * c, 64, 0, st>>>(parts, np, 2 * c, sums);
+        LCF_CHECK_LAUNCH();
+        bn8_apply_relu_kernel<<<np, BN_BLOCK, 0, st>>>((const __bf16 *)x, k, c, rpb, sums, gamma,
+                                                      beta, eps, relu, (__bf16 *)y, stats, run);
+        LCF_CHECK_LAUNCH();
+        return LCF_OK;
+    }
     if (x_bf16)
         bn_stats_kernel<__bf16><<<np, BN_BLOCK, 0, st>>>((const __bf16 *)x, k, c, rpb, parts);
     else
@@ -376,8 +594,42 @@ extern "C" int lcf_bn_relu_bwd_ex(const void *x, int x_bf16, const void *y, int 
     case 5: return bn_bwd_launch<float, __bf16, float, __bf16>(x, y, dy, k, c, gamma, stats, relu, dx, dgamma, dbeta, ws, st);
     case 6: return bn_bwd_launch<float, __bf16, __bf16, float>(x, y, dy, k, c, gamma, stats, relu, dx, dgamma, dbeta, ws, st);
     case 7: return bn_bwd_launch<float, __bf16, __bf16, __bf16>(x, y, dy, k, c, gamma, stats, relu, dx, dgamma, dbeta, ws, st);
-    default: return LCF_ERR_UNSUPPORTED; // bf16 x (conv outputs stay fp32)
+    // everything bf16: the dense RPN's BatchNorm2d + ReLU on channels_last activations under
+    // bf16 autocast (rows = pixels; objectdetection_amd/rpn.py)
+    case 15: return bn_bwd_launch<__bf16, __bf16, __bf16, __bf16>(x, y, dy, k, c, gamma, stats, relu, dx, dgamma, dbeta, ws, st);
+    default: return LCF_ERR_UNSUPPORTED; // other mixes with a bf16 x are not built
     }
+}
+
+extern "C" int lcf_bn_relu_bwd_b16(const void *x_bf16, const void *dy_bf16, int k, int c,
+                                   const float *gamma, const float *beta, const float *stats,
+                                   int relu, void *dx_bf16, float *dgamma, float *dbeta, void *ws,
+                                   size_t ws_bytes, void *stream)
+{
+    int rc = bn_check(k, c);
+    if (rc) return rc;
+    if (c & 7) return LCF_ERR_UNSUPPORTED;
+    if (!x_bf16 || !dy_bf16 || !dx_bf16 || !stats || !ws) return LCF_ERR_ARG;
+    if (((uintptr_t)x_bf16 & 15) || ((uintptr_t)dy_bf16 & 15) || ((uintptr_t)dx_bf16 & 15) ||
+        ((uintptr_t)stats & 15))
+        return LCF_ERR_ARG;
+    if (ws_bytes < lcf_bn_workspace_bytes(k, c)) return LCF_ERR_WORKSPACE;
+    int rpb, np;
+    bn_partition(k, &rpb, &np);
+    hipStream_t st = (hipStream_t)stream;
+    float *parts = (float *)ws;
+    double *sums = (double *)((char *)ws + (size_t)BN_MAX_PARTS * 2 * c * sizeof(float));
+    bn8_bwd_reduce_kernel<<<np, BN_BLOCK, 0, st>>>((const __bf16 *)x_bf16,
+                                                   (const __bf16 *)dy_bf16, k, c, rpb, stats,
+                                                   gamma, beta, relu, parts);
+    LCF_CHECK_LAUNCH();
+    bn_finalize_kernel<<<2 * c, 64, 0, st>>>(parts, np, 2 * c, sums);
+    LCF_CHECK_LAUNCH();
+    bn8_bwd_apply_kernel<<<np, BN_BLOCK, 0, st>>>((const __bf16 *)x_bf16, (const __bf16 *)dy_bf16,
+                                                  k, c, rpb, stats, sums, gamma, beta, relu,
+                                                  (__bf16 *)dx_bf16, dgamma, dbeta);
+    LCF_CHECK_LAUNCH();
+    return LCF_OK;
 }
 
 extern "C" int lcf_bn_relu_bwd(const float *x, const float *y, const float *dy, int k, int c,

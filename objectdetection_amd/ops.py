@@ -1096,6 +1096,73 @@ def vfe_layer_train(x, xp, wp, seg, norm, n, k, mode):
     return out
 
 
+class BNReLUNHWCFunction(torch.autograd.Function):
+    """nn.BatchNorm2d (training) + ReLU on a channels_last bfloat16 activation [N,C,H,W] -- the
+    dense RPN under bf16 autocast -- as the row kernels of the sparse path (rows = the N*H*W
+    pixels, contiguous in channels_last memory): two passes forward (statistics; normalise +
+    ReLU, bf16 out, running statistics updated in the kernel) and two backward, where the library
+    route (MIOpen's three-kernel BatchNorm + a separate ReLU / threshold_backward) makes five and
+    four passes over the 72 MB tensor."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, run):
+        L = _lib.lib()
+        n, c, h, w = x.shape
+        rows = x.permute(0, 2, 3, 1)  # [N,H,W,C] view of channels_last memory
+        if not rows.is_contiguous():
+            rows = rows.contiguous()
+        k = n * h * w
+        y = torch.empty((n, h, w, c), dtype=torch.bfloat16, device=x.device)
+        stats = torch.empty((3 * c,), dtype=torch.float32, device=x.device)
+        ws = _ws(L.lcf_bn_workspace_bytes(k, c), x.device)
+        g = gamma.detach().float().contiguous()
+        b = beta.detach().float().contiguous()
+        rm = rv = nbt = None
+        mom = 0.0
+        if run is not None:
+            rm, rv, nbt, mom = run
+        check(L.lcf_bn_relu_fwd_ex(_ptr(rows), 1, k, c, _ptr(g), _ptr(b), float(eps), 1, _ptr(y),
+                                   1, _ptr(stats), _ptr(rm), _ptr(rv), _ptr(nbt), float(mom),
+                                   _ptr(ws), ws.numel(), _stream()))
+        ctx.save_for_backward(rows, g, b, stats)
+        ctx.mark_non_differentiable(stats)
+        return y.permute(0, 3, 1, 2), stats
+
+    @staticmethod
+    def backward(ctx, dy, _dstats):
+        L = _lib.lib()
+        rows, g, b, stats = ctx.saved_tensors
+        n, h, w, c = rows.shape
+        k = n * h * w
+        dyr = dy.to(torch.bfloat16).permute(0, 2, 3, 1)
+        if not dyr.is_contiguous():
+            dyr = dyr.contiguous()
+        dev = rows.device
+        dx = torch.empty((n, h, w, c), dtype=torch.bfloat16, device=dev)
+        dg = torch.empty((c,), dtype=torch.float32, device=dev)
+        db = torch.empty((c,), dtype=torch.float32, device=dev)
+        ws = _ws(L.lcf_bn_workspace_bytes(k, c), dev)
+        check(L.lcf_bn_relu_bwd_b16(_ptr(rows), _ptr(dyr), k, c, _ptr(g), _ptr(b), _ptr(stats), 1,
+                                    _ptr(dx), _ptr(dg), _ptr(db), _ptr(ws), ws.numel(),
+                                    _stream()))
+        return dx.permute(0, 3, 1, 2), dg, db, None, None
+
+
+def bn_relu_nhwc_supported(norm, x):
+    return (isinstance(norm, torch.nn.BatchNorm2d) and norm.training and norm.affine
+            and x.is_cuda and x.dim() == 4 and x.dtype == torch.bfloat16
+            and x.shape[1] % 8 == 0 and x.shape[1] <= 128 and x.numel() > 0
+            and x.is_contiguous(memory_format=torch.channels_last)
+            and norm.weight.dtype == torch.float32 and _bn_running(norm) is not None)
+
+
+def bn_relu_train_nhwc(norm, x):
+    """relu(norm(x)) for a training-mode nn.BatchNorm2d on a channels_last bfloat16 x (see
+    BNReLUNHWCFunction); running statistics updated as the module would."""
+    y, _ = BNReLUNHWCFunction.apply(x, norm.weight, norm.bias, norm.eps, _bn_running(norm))
+    return y
+
+
 def _bn_running(norm):
     """(running_mean, running_var, num_batches_tracked, momentum) for the kernels that update the
     running statistics themselves, or None (no tracking, cumulative averaging, non-fp32 buffers:

@@ -61,12 +61,33 @@ class RPNV2(nn.Module):
         if use_direction_classifier:
             self.conv_dir_cls = nn.Conv2d(final, num_anchor_per_loc * num_direction_bins, 1)
 
+    # training under bf16 autocast on channels_last activations: BatchNorm2d + ReLU pairs run as
+    # liblcf's two-pass row kernels (ops.bn_relu_train_nhwc) instead of MIOpen's BatchNorm plus a
+    # separate ReLU; False keeps the stock modules
+    fuse_bn_relu = True
+
+    def _run(self, seq, x):
+        """nn.Sequential ``seq`` on x, with (BatchNorm2d, ReLU) pairs fused where that applies."""
+        from . import ops
+        mods = list(seq)
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            if (self.fuse_bn_relu and torch.is_grad_enabled() and i + 1 < len(mods)
+                    and isinstance(mods[i + 1], nn.ReLU) and ops.bn_relu_nhwc_supported(m, x)):
+                x = ops.bn_relu_train_nhwc(m, x)
+                i += 2
+                continue
+            x = m(x)
+            i += 1
+        return x
+
     def forward(self, x):
         ups = []
         for i, block in enumerate(self.blocks):
-            x = block(x)
+            x = self._run(block, x)
             if i - self._upsample_start_idx >= 0:
-                ups.append(self.deblocks[i - self._upsample_start_idx](x))
+                ups.append(self._run(self.deblocks[i - self._upsample_start_idx], x))
         if ups:
             x = torch.cat(ups, dim=1)
         box = self.conv_box(x)

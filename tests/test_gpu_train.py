@@ -173,3 +173,58 @@ def test_batch8_bf16_middle_gradients_match_oracle_replay(cuda, oracle):
     assert max(e) < 3e-3, ("fp32 vs fp32 replay", e)
     e = errs(g16, ref32)
     assert e[-1] < 2e-2 and e[-2] < 2e-2 and max(e) < 0.3, ("bf16 vs fp32 replay", e)
+
+
+def test_rpn_fused_batchnorm_relu_matches_the_stock_modules(cuda):
+    """ops.bn_relu_train_nhwc (BatchNorm2d + ReLU of the RPN on channels_last bf16 activations as
+    liblcf's row kernels) against nn.BatchNorm2d + nn.ReLU on the same bf16 input under autocast:
+    output (one bf16 ulp), input / weight / bias gradients, running statistics; and RPNV2 as a
+    whole with and without the fusion."""
+    import copy
+    torch.manual_seed(0)
+    bn = torch.nn.BatchNorm2d(128, eps=1e-3, momentum=0.01).to(cuda).train()
+    torch.nn.init.uniform_(bn.weight, 0.5, 1.5)
+    torch.nn.init.normal_(bn.bias, std=0.3)
+    ref = copy.deepcopy(bn)
+    x = (torch.randn(2, 128, 50, 44, device=cuda) * 2 + 0.5).bfloat16().contiguous(
+        memory_format=torch.channels_last)
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    assert ops.bn_relu_nhwc_supported(bn, xa)
+    ya = ops.bn_relu_train_nhwc(bn, xa)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        yb = torch.relu(ref(xb))
+    assert ya.dtype == torch.bfloat16 and ya.shape == yb.shape
+    assert ya.is_contiguous(memory_format=torch.channels_last)
+    scale = float(yb.detach().float().abs().max())
+    assert float((ya.detach().float() - yb.detach().float()).abs().max()) / scale < 1e-2  # a bf16 ulp
+    g = torch.randn_like(ya)
+    ya.backward(g)
+    yb.backward(g)
+    rel = lambda a, b: float((a.float() - b.float()).norm() / b.float().norm())
+    assert rel(xa.grad, xb.grad) < 1e-2
+    assert rel(bn.weight.grad, ref.weight.grad) < 5e-3 and rel(bn.bias.grad, ref.bias.grad) < 5e-3
+    assert torch.allclose(bn.running_mean, ref.running_mean, rtol=1e-3, atol=1e-5)
+    assert torch.allclose(bn.running_var, ref.running_var, rtol=1e-3, atol=1e-5)
+    assert int(bn.num_batches_tracked) == 1
+    # the whole head: bf16 activations through seven conv + BatchNorm layers amplify any
+    # rounding difference, so the yardstick is the fp32 head -- the fused path must be as close
+    # to it as the stock bf16 path is -- and the layer next to the loss, where nothing has been
+    # amplified yet
+    from objectdetection_amd.rpn import RPNV2
+    a = RPNV2().to(cuda).train().to(memory_format=torch.channels_last)
+    b, c = copy.deepcopy(a), copy.deepcopy(a)
+    b.fuse_bn_relu = False
+    xin = torch.randn(2, 128, 40, 48, device=cuda).bfloat16().contiguous(
+        memory_format=torch.channels_last)
+    grads = []
+    for net, amp in ((a, True), (b, True), (c, False)):
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
+            p = net(xin if amp else xin.float())
+        loss = sum(v.float().pow(2).mean() for v in p.values())
+        loss.backward()
+        grads.append((loss.item(), net.blocks[0][1].weight.grad.float().clone(),
+                      net.deblocks[0][0].weight.grad.float().clone()))
+    (la, ga0, ga1), (lb, gb0, gb1), (lc, gc0, gc1) = grads
+    assert abs(la - lc) / abs(lc) < 2e-2 and abs(lb - lc) / abs(lc) < 2e-2
+    assert rel(ga1, gc1) < max(1.5 * rel(gb1, gc1), 2e-2)   # last conv in front of the heads
+    assert rel(ga0, gc0) < max(1.5 * rel(gb0, gc0), 5e-2)   # first conv: fully amplified
