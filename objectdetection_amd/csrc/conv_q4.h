@@ -26,6 +26,10 @@
 // (0.695 -> 0.636 ms per frame, tools/ab_q4.py): the default for 27-offset convs with 32 / 64
 // channels.  LCF_OPT_CONV_IMPL = 2 keeps the tile-compacted kernel, 5 asks for this one;
 // LCF_OPT_CONV_SETS = 1..4 waves per tile (default 3 at 32 input channels, 4 at 64).
+// -DQ4_ABLATE=<bits> (round 3; timing only, results are wrong): 1 = W[o] loaded once per wave,
+// 2 = every gather from 64 cached rows, 4 = results summed in registers (no LDS tile), 8 = set-up
+// and epilogue only, 16 = no MFMAs.  tools/ubench/q4_ablate.sh runs such builds through
+// tools/bench_q4.py; DESIGN.md section 8 (round 3) has the numbers.
 #pragma once
 
 template <int CIN, int COUT, int KS_>
@@ -144,7 +148,11 @@ cv_q4_kernel(const float *__restrict__ feat, const float *__restrict__ wimg,
     auto gather = [&](int ibase, int g) -> AReg {
         AReg a;
         const unsigned e = ent[ibase + R * g + rg];
+#if defined(Q4_ABLATE) && (Q4_ABLATE & 2) // timing ablation: every gather hits one of 64 cached rows
+        const float *src = fbase + (size_t)((e >> 7) & 63) * CIN;
+#else
         const float *src = fbase + (size_t)(e >> 7) * CIN;
+#endif
         if constexpr (CPL == 8) {
             const float4 x = reinterpret_cast<const float4 *>(src)[0];
             const float4 y = reinterpret_cast<const float4 *>(src)[1];
@@ -178,7 +186,14 @@ cv_q4_kernel(const float *__restrict__ feat, const float *__restrict__ wimg,
         }
     };
     // tile[output rows of the group][col] += result (vgpr i = row 4h + i of the group)
+#if defined(Q4_ABLATE) && (Q4_ABLATE & 4) // timing ablation: results summed in registers, no LDS tile
+    f32x4 sink = {0.f, 0.f, 0.f, 0.f};
+#endif
     auto add_out = [&](const f32x4 &acc, int ibase, int g) {
+#if defined(Q4_ABLATE) && (Q4_ABLATE & 4)
+        sink += acc;
+        return;
+#endif
         const uint4 e4 = *reinterpret_cast<const uint4 *>(ent + ibase + R * g + 4 * h);
         float *p0 = ot + (e4.x & 127u) * OSTR + col;
         float *p1 = ot + (e4.y & 127u) * OSTR + col;
@@ -191,7 +206,11 @@ cv_q4_kernel(const float *__restrict__ feat, const float *__restrict__ wimg,
         *p3 = c3 + acc[3];
     };
 
+#if defined(Q4_ABLATE) && (Q4_ABLATE & 8) // timing ablation: set-up and epilogue only
+    if (false) {
+#else
     if (set < n_steps) {
+#endif
         // Everything that steers is wave-uniform (SGPRs).  Step metadata of this step and the next.
         int s = set;
         int o = __builtin_amdgcn_readfirstlane(soff[s]);
@@ -228,6 +247,14 @@ cv_q4_kernel(const float *__restrict__ feat, const float *__restrict__ wimg,
             n0 = gather(pib, pg);
             n1 = gather(pib, pg + 1 < png ? pg + 1 : pg);
             f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
+#if defined(Q4_ABLATE) && (Q4_ABLATE & 16) // timing ablation: no MFMAs (operands kept alive)
+            if (true) {
+                c0[0] = a0.v[0] + w[0] + w[CW - 1];
+                c1[0] = a1.v[CPL - 1] + w[1] + w[CW / 2];
+                add_out(c0, ib, g);
+                if (g + 1 < ng) add_out(c1, ib, g + 1);
+            } else
+#endif
             if (g + 1 < ng) {
                 f32x4 p0[2] = {c0, c0}, p1[2] = {c0, c0};
                 Q4Mac<CIN, COUT, KS, 0>::two(a0.v, a1.v, w, p0, p1);
@@ -246,7 +273,9 @@ cv_q4_kernel(const float *__restrict__ feat, const float *__restrict__ wimg,
             if (!more) break;
             g = pg;
             if (newstep) {
+#if !(defined(Q4_ABLATE) && (Q4_ABLATE & 1)) // timing ablation: W[o] loaded once per wave
                 bload(no, w);
+#endif
                 s += NSETS;
                 o = no;
                 ng = nng;
@@ -255,6 +284,9 @@ cv_q4_kernel(const float *__restrict__ feat, const float *__restrict__ wimg,
             }
         }
     }
+#if defined(Q4_ABLATE) && (Q4_ABLATE & 4)
+    ot[col] = sink[0] + sink[1] + sink[2] + sink[3];
+#endif
     __syncthreads();
 
     // ---- epilogue: sum of the waves' tiles (wave 0 first), (x*scale + shift), relu, store

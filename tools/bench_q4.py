@@ -44,6 +44,8 @@ def main():
             x = conv(x, _scale=scale, _shift=shift, _relu=True)
     torch.cuda.synchronize()
     variants = [("tc", 2, 0), ("q4x1", 5, 1), ("q4x2", 5, 2), ("q4x3", 5, 3), ("q4x4", 5, 4)]
+    if os.environ.get("Q4_ONLY"):  # e.g. Q4_ONLY=q4x4 (timing ablation builds: one variant)
+        variants = [v for v in variants if v[0] in os.environ["Q4_ONLY"].split(",")]
     tiles = [0] + [int(t) for t in os.environ.get("Q4_TILES", "").split(",") if t]
     reps, rounds = 10, 5
     res = {}
@@ -75,6 +77,8 @@ def main():
         print(row)
     print("total us:", {f"{v}/t{t}": round(x, 1) for (v, t), x in tot.items()})
     # errors against a float64 reference, relative to the output's max magnitude
+    if os.environ.get("Q4_NOERR"):
+        layers = []
     for li, (name, args, pairs, w) in enumerate(layers):
         x, _, nbr, k_out, kvol, cin, cout, scale, shift, relu = args
         wd = w.detach().double().reshape(kvol, cin, cout)
