@@ -417,6 +417,29 @@ int lcf_indice_conv_fwd_b16(const void *feat_bf16, int k_in, const void *wimg_bf
 int lcf_indice_conv_wgrad_b16(const void *feat_bf16, const void *dout_bf16, const int *in_nbr,
                               int k_in, int kvol, int cin, int cout, float *dw, void *stream);
 
+/* Inference on three exact bf16 planes, six products ("bf16x6"; round 3).  Replaces, for the
+ * 27-offset convs of 32 / 64 channels of one frame, the same reference call as
+ * lcf_indice_conv_fwd (spconv SparseConvolution.forward -> indice_conv,
+ * second/pytorch/models/middle.py:145-192) with fp32-GRADE arithmetic on the bf16 matrix cores:
+ * an fp32 value is exactly h + m + l with three bf16 numbers, and x*w = hH + (hM + mH) +
+ * (hL + lH + mM) up to 2^-24 |x*w|; all six products are exact in the fp32 accumulator.
+ * Measured distance from a float64 reference: the same as the fp32 MFMA kernels' (a few 1e-7 of
+ * the result's max magnitude; tests/test_gpu_conv.py).
+ * Rows travel BETWEEN such convs as planes: [3][plane_rows][c] bf16, plane p at byte offset
+ * p * plane_rows * c * 2 (plane_rows * c * 2 < 2 GB and a multiple of 16).
+ * lcf_split_planes: feat [k,c] fp32 -> planes (rows >= the count are left untouched).
+ * lcf_indice_conv_fwd_x6: feat_planes as above, wimg_planes = lcf_weight_image_bf16x8 (its three
+ *   planes), nbr [k_out,kvol] (every entry < plane_rows), k_out / k_out_dev as everywhere;
+ *   y = relu?((sum) * scale + shift) (scale / shift may be NULL); out = fp32 rows [k_out,cout]
+ *   (out_planes = 0) or planes [3][out_plane_rows][cout] (out_planes = 1, out_plane_rows >= k_out).
+ *   (cin, cout) in {(32,32), (32,64), (64,64)}.  Deterministic, no workspace, no tile plan. */
+int lcf_split_planes(const float *feat, int k, const int *k_dev, int c, void *planes,
+                     int plane_rows, void *stream);
+int lcf_indice_conv_fwd_x6(const void *feat_planes, int plane_rows, const void *wimg_planes,
+                           const int *nbr, int k_out, const int *k_out_dev, int kvol, int cin,
+                           int cout, const float *scale, const float *shift, int relu, void *out,
+                           int out_planes, int out_plane_rows, void *stream);
+
 /* Frame hand-over for a caller that keeps a static point buffer and a device-side point count
  * (FrameEngine; no counterpart in the reference): dst[0 : n*f] = points[0 : n*f] and
  * n_dev[0] = n_total (>= n: dst may point behind points already in the buffer, the light-curtain

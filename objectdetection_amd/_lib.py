@@ -121,6 +121,10 @@ SYMBOLS = {
                                         c_int, c_void_p, c_int, c_void_p]),
     "lcf_indice_conv_wgrad_b16": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                           c_int, c_void_p, c_void_p]),
+    "lcf_split_planes": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p]),
+    "lcf_indice_conv_fwd_x6": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int,
+                                       c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int,
+                                       c_int, c_void_p]),
     "lcf_dense_nhwc_bf16_rows": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int,
                                          _PI3, c_int, c_void_p, c_void_p]),
     "lcf_dense_nhwc_bf16_bwd_rows": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, _PI3,

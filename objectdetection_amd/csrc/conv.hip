@@ -2011,6 +2011,7 @@ cv_wgrad_mc_kernel(const float *__restrict__ feat, const float *__restrict__ dou
 }
 
 #include "conv_bt.h" // bf16-row training kernels (forward / dgrad / wgrad), round 3
+#include "conv_bx.h" // inference on three exact bf16 planes, six products (round 3)
 
 // -------------------------------------------------------------------------- host side
 

@@ -55,12 +55,15 @@ class FrameEngine:
         inside the 1e-4 feature tolerance; layers with 32/64/128 channels on both sides) or
         "bf16x8" (three exact bf16 planes, eight products: fp32-grade results, ~1e-7, at half the
         matrix-pipe cycles of the fp32 MFMA; the 64-channel layers only -- it does not pay on
-        the 32-channel ones).
+        the 32-channel ones) or "bf16x6" (round 3: rows travel between the layers as three
+        exact bf16 planes, six products, no compaction, no tile plans -- lcf_indice_conv_fwd_x6;
+        the same distance from float64 as the fp32 kernels; used on the layers where it measured
+        ahead of the fp32 quad-row kernel at the calibrated row counts, the others stay fp32).
         dense_out: a contiguous [1,C,D,H,W] float32 cuda tensor the frame's dense output is written
         to instead of a buffer of the engine's own (FrameBatch: a slice of the batch's output)."""
         self._dense_out = dense_out
-        if conv_math not in ("f32", "bf16x3", "bf16x8"):
-            raise ValueError("conv_math must be 'f32', 'bf16x3' or 'bf16x8'")
+        if conv_math not in ("f32", "bf16x3", "bf16x8", "bf16x6"):
+            raise ValueError("conv_math must be 'f32', 'bf16x3', 'bf16x8' or 'bf16x6'")
         self.conv_math = conv_math
         p = next(model.parameters(), None)
         self.dev = p.device if p is not None else torch.device("cuda", torch.cuda.current_device())
@@ -181,6 +184,11 @@ class FrameEngine:
                 l.planes = 3 if self.conv_math == "bf16x8" else 2
                 l.wimg = ops.weight_image_bf16x3(l.conv.weight, planes=l.planes) if l.x3 \
                     else ops.weight_image(l.conv.weight)
+                # "bf16x6": rows as three exact bf16 planes, six products (csrc/conv_bx.h);
+                # which of the candidate layers run it is decided per frame size in _plan
+                l.x6_ok = (self.conv_math == "bf16x6" and l is not self.layers[-1] and
+                           ops.x6_conv_supported(l.cin, l.cout, l.kvol))
+                l.wimg3 = ops.weight_image_bf16x3(l.conv.weight, planes=3) if l.x6_ok else None
                 scale = shift = None
                 if l.bn is not None:
                     scale, shift = _bn_affine(l.bn)
@@ -268,10 +276,37 @@ class FrameEngine:
         # re-deriving it; the tile height is the one the forward would pick for the rows expected
         plan_rows, lvl = {}, 0
         self.use_plans = os.environ.get("LCF_ENGINE_TILE_PLANS", "1") != "0"
+        # conv_math="bf16x6": the six-product kernel on the layers where it measured ahead of the
+        # fp32 quad-row kernel ALONE (tools/bench_bx.py): the 32 -> 32 layers (22 against 31 us at
+        # 46k rows) and the 64 -> 64 ones while one workgroup per CU holds all rows (<= 256 tiles of
+        # 64 rows: 33 against 40 us at 15.5k rows; 47 against 42 at 18.6k, 69 against 72 at 38k).
+        # In the frame, beside the rulebook branch, that advantage is gone (tools/ab_x6.sh:
+        # 1638 frames/s against 1641 with the fp32 kernels; on every candidate layer 1439), which
+        # is why "f32" stays the default.  LCF_ENGINE_X6 = all | none overrides.  Calibration (no
+        # row counts yet) runs the fp32 kernels.
+        x6_mode = os.environ.get("LCF_ENGINE_X6", "auto")
+        need0 = getattr(self, "level_need", None)
         for l in self.layers:
             if not l.subm:
                 lvl += 1
-            l.planned = (self.use_plans and l.kvol > 1 and
+            rows_exp = int(need0[lvl]) if need0 else 0
+            l.use_x6 = bool(getattr(l, "x6_ok", False) and need0 and x6_mode != "none" and (
+                x6_mode == "all" or (l.cin == 32 and l.cout == 32) or
+                (l.cin == 64 and l.cout == 64 and (rows_exp + 63) // 64 <= 256)))
+        for i, l in enumerate(self.layers):
+            nxt = self.layers[i + 1] if i + 1 < len(self.layers) else None
+            prv = self.layers[i - 1] if i > 0 else None
+            l.out_planes = bool(l.use_x6 and nxt is not None and nxt.use_x6)
+            l.split_in = bool(l.use_x6 and not (prv is not None and prv.use_x6))
+            l.out3 = torch.zeros((3, l.k_out_cap, l.cout), dtype=torch.bfloat16, device=dev) \
+                if l.out_planes else None
+            l.in3 = torch.zeros((3, l.k_in_cap, l.cin), dtype=torch.bfloat16, device=dev) \
+                if l.split_in else None
+        lvl = 0
+        for l in self.layers:
+            if not l.subm:
+                lvl += 1
+            l.planned = (self.use_plans and l.kvol > 1 and not l.use_x6 and
                          ops.bf16_supported(l.cin, l.cout))
             if l.planned:
                 need = getattr(self, "level_need", None)
@@ -458,6 +493,7 @@ class FrameEngine:
         if order == "vfe_first":
             side_parts(last_part)
         feat, coors = self.feat0, self.coors
+        feat3 = None  # the rows as three bf16 planes, between two "bf16x6" layers
         waited = set()
         lvl = 0
         for l in self.layers:
@@ -468,6 +504,7 @@ class FrameEngine:
                 if self.two_streams:
                     main.wait_event(ready[id(o)])
                 waited.add(id(o))
+            kd_in = kd
             if l.subm:
                 k_out_cap, k_out_dev = l.k_in_cap, kd
             else:
@@ -483,7 +520,17 @@ class FrameEngine:
             if to_dense and self.two_streams:
                 side_parts(last_part)
                 main.wait_event(side_state["e_dense"])
-            if l.planned:
+            if l.use_x6:
+                if l.split_in:
+                    check(L.lcf_split_planes(P(feat), l.k_in_cap, P(kd_in), l.cin, P(l.in3),
+                                             l.k_in_cap, st))
+                    feat3 = l.in3
+                check(L.lcf_indice_conv_fwd_x6(
+                    P(feat3), feat3.shape[1], P(l.wimg3), P(o.nbr), k_out_cap, P(k_out_dev),
+                    l.kvol, l.cin, l.cout, P(l.scale), P(l.shift), int(l.relu),
+                    P(l.out3 if l.out_planes else l.out), int(l.out_planes), k_out_cap, st))
+                feat3 = l.out3
+            elif l.planned:
                 lv = o.level
                 check(L.lcf_indice_conv_fwd_planned(
                     P(feat), P(l.wimg), (3 if l.planes == 3 else 2) if l.x3 else 0,

@@ -703,6 +703,46 @@ def conv_wgrad_b16(features, dout, in_nbr, kvol, cin, cout):
     return dw
 
 
+def x6_conv_supported(cin, cout, kvol=27):
+    """Layers lcf_indice_conv_fwd_x6 is built for."""
+    return (cin, cout) in ((32, 32), (32, 64), (64, 64)) and kvol > 1
+
+
+def split_planes(features, n_rows_dev=None, plane_rows=None, out=None):
+    """fp32 rows [k, c] -> three exact bf16 planes [3, plane_rows, c] (lcf_split_planes): an fp32
+    value is h + m + l with h = bf16(x), m = bf16(x - h), l = bf16(x - h - m)."""
+    _need_cuda(features)
+    x = features.contiguous()
+    k, c = int(x.shape[0]), int(x.shape[1])
+    rows = k if plane_rows is None else int(plane_rows)
+    if out is None:
+        out = torch.zeros((3, rows, c), dtype=torch.bfloat16, device=x.device)
+    check(_lib.lib().lcf_split_planes(_ptr(x), k, _ptr(n_rows_dev), c, _ptr(out), rows, _stream()))
+    return out
+
+
+def conv_forward_x6(planes, wimg3, nbr, n_rows, kvol, cin, cout, scale=None, shift=None,
+                    relu=False, n_rows_dev=None, out_planes=False, out=None):
+    """indice_conv on three exact bf16 planes with six products (include/lcf.h:
+    lcf_indice_conv_fwd_x6): planes [3, rows, cin] bfloat16 (split_planes or a previous call with
+    ``out_planes``), wimg3 = weight_image_bf16x3(weight, planes=3) -> [n_rows, cout] float32, or
+    [3, n_rows, cout] bfloat16 planes for the next such conv.  fp32-grade results."""
+    _need_cuda(planes, wimg3, nbr)
+    if planes.dtype != torch.bfloat16 or planes.dim() != 3 or planes.shape[0] != 3:
+        raise ValueError("conv_forward_x6 takes [3, rows, cin] bfloat16 planes")
+    x = planes.contiguous()
+    if out is None:
+        out = (torch.zeros((3, int(n_rows), int(cout)), dtype=torch.bfloat16, device=x.device)
+               if out_planes else
+               torch.empty((int(n_rows), int(cout)), dtype=torch.float32, device=x.device))
+    out_rows = int(out.shape[1]) if out_planes else int(n_rows)
+    check(_lib.lib().lcf_indice_conv_fwd_x6(_ptr(x), int(x.shape[1]), _ptr(wimg3), _ptr(nbr),
+                                            int(n_rows), _ptr(n_rows_dev), int(kvol), int(cin),
+                                            int(cout), _ptr(scale), _ptr(shift), int(bool(relu)),
+                                            _ptr(out), int(bool(out_planes)), out_rows, _stream()))
+    return out
+
+
 def b16_conv_supported(cin, cout):
     """Channel pairs the bf16-row training kernels (forward, dgrad and wgrad) are built for."""
     return cin in (32, 64) and cout in (32, 64)

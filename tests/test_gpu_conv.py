@@ -932,3 +932,84 @@ def test_all_ones_kernel_is_a_row_gemm_at_any_width(cuda):
             z = conv(spconv.SparseConvTensor(x.detach(), idx, [41, 1600, 1408], 1), _scale=sc,
                      _shift=sh, _relu=True)
             assert torch.allclose(z.features, torch.relu(ref * sc + sh), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("cin,cout,subm,batch", [(32, 32, True, 1), (64, 64, True, 2),
+                                                 (32, 64, False, 1), (64, 64, False, 1)])
+def test_six_product_planes_form_is_fp32_grade(oracle, cuda, cin, cout, subm, batch):
+    """lcf_indice_conv_fwd_x6 (three exact bf16 planes, six products; csrc/conv_bx.h) through the C
+    ABI: within the fp32 tolerance of the oracle (1e-4), and at the SAME distance from a float64
+    reference as the fp32 MFMA kernel on the same inputs (both a few 1e-7 of the result's max
+    magnitude; the bound asserted is 2.5 x the fp32 kernel's own distance + 1e-7).  Planes written by
+    the kernel's epilogue sum to its fp32 output exactly; a second conv fed with those planes
+    matches the fp32 kernel fed with the fp32 rows; a device-side count below the capacity leaves
+    the rows beyond it untouched."""
+    from objectdetection_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(7 + cin + cout + batch)
+    parts = []
+    for b in range(batch):
+        c = _frame_coors(oracle, 4 + b, 6000)
+        c[:, 0] = b
+        parts.append(c)
+    coors = np.ascontiguousarray(np.concatenate(parts))
+    shape = [41, 1600, 1408]
+    k = coors.shape[0]
+    x = np.abs(rng.standard_normal((k, cin))).astype(np.float32) * rng.random((k, 1), np.float32)
+    w = (rng.standard_normal((3, 3, 3, cin, cout)) / np.sqrt(27 * cin)).astype(np.float32)
+    scale = (rng.random(cout) + 0.5).astype(np.float32)
+    shift = (rng.standard_normal(cout) * 0.1).astype(np.float32)
+    if subm:
+        pairs, pn = oracle.rulebook_subm(coors, batch, shape, 3)
+        k_out = k
+    else:
+        oc, pairs, pn, _ = oracle.rulebook_conv(coors, batch, shape, 3, 2, 1)
+        k_out = oc.shape[0]
+    ref32 = np.maximum(oracle.indice_conv_fwd(x, w, pairs, pn, k_out) * scale + shift, 0)
+    rb = ops.build_rulebook(torch.from_numpy(coors).to(cuda), batch, shape, 3, 2, 1, 1, subm)
+    assert rb.k_out == k_out
+    xt, wt = torch.from_numpy(x).to(cuda), torch.from_numpy(w).to(cuda)
+    sc, sh = torch.from_numpy(scale).to(cuda), torch.from_numpy(shift).to(cuda)
+    # float64 reference on the device
+    wd = wt.double().reshape(27, cin, cout)
+    ref64 = torch.zeros((k_out, cout), dtype=torch.float64, device=cuda)
+    for o in range(27):
+        idx = rb.out_nbr[:, o].long()
+        v = idx >= 0
+        ref64[v] += xt[idx[v]].double() @ wd[o]
+    ref64 = torch.relu(ref64 * sc.double() + sh.double())
+    dist = lambda t: float((t.double() - ref64).abs().max() / ref64.abs().max())
+    y32 = ops.conv_forward(xt, ops.weight_image(wt), rb.out_nbr, k_out, 27, cin, cout, sc, sh, True)
+    st = torch.cuda.current_stream().cuda_stream
+    planes = torch.zeros((3, k + 5, cin), dtype=torch.bfloat16, device=cuda)
+    assert L.lcf_split_planes(xt.data_ptr(), k, None, cin, planes.data_ptr(), k + 5, st) == 0
+    assert torch.equal(planes[:, :k].float().sum(0), xt)  # h + m + l == x, exactly
+    wimg3 = ops.weight_image_bf16x3(wt, planes=3)
+    y = torch.full((k_out + 3, cout), 7.0, device=cuda)
+    kd = torch.tensor([k_out], dtype=torch.int32, device=cuda)
+    assert L.lcf_indice_conv_fwd_x6(planes.data_ptr(), k + 5, wimg3.data_ptr(),
+                                    rb.out_nbr.data_ptr(), k_out + 3, kd.data_ptr(), 27, cin, cout,
+                                    sc.data_ptr(), sh.data_ptr(), 1, y.data_ptr(), 0, 0, st) == 0
+    yp = torch.zeros((3, k_out + 3, cout), dtype=torch.bfloat16, device=cuda)
+    assert L.lcf_indice_conv_fwd_x6(planes.data_ptr(), k + 5, wimg3.data_ptr(),
+                                    rb.out_nbr.data_ptr(), k_out + 3, kd.data_ptr(), 27, cin, cout,
+                                    sc.data_ptr(), sh.data_ptr(), 1, yp.data_ptr(), 1, k_out + 3,
+                                    st) == 0
+    torch.cuda.synchronize()
+    assert bool((y[k_out:] == 7.0).all()) and bool((yp[:, k_out:] == 0).all())
+    assert rel_err(y[:k_out].cpu().numpy(), ref32) < 1e-4          # the oracle, fp32 tolerance
+    d6, d32 = dist(y[:k_out]), dist(y32)
+    assert d6 < 2.5 * d32 + 1e-7 and d6 < 1e-6, (d6, d32)           # fp32-grade
+    assert torch.equal(yp[:, :k_out].float().sum(0), y[:k_out])     # the planes ARE the fp32 result
+    y2 = ops.conv_forward_x6(planes, wimg3, rb.out_nbr, k_out, 27, cin, cout, sc, sh, True)
+    assert torch.equal(y2, y[:k_out])                               # deterministic
+    if subm and cin == cout:  # a second layer on the planes the first one wrote
+        z6 = ops.conv_forward_x6(yp[:, :k_out].contiguous(), wimg3, rb.out_nbr, k_out, 27, cin, cout)
+        z32 = ops.conv_forward(y32, ops.weight_image(wt), rb.out_nbr, k_out, 27, cin, cout)
+        assert float((z6 - z32).abs().max() / z32.abs().max()) < 2e-6
+    # refused: unsupported widths, planes that are not 16-byte multiples apart, missing table
+    assert L.lcf_indice_conv_fwd_x6(planes.data_ptr(), k + 5, wimg3.data_ptr(),
+                                    rb.out_nbr.data_ptr(), k_out, None, 27, 16, cout, None, None, 0,
+                                    y.data_ptr(), 0, 0, st) == -3
+    assert L.lcf_indice_conv_fwd_x6(planes.data_ptr(), k + 5, wimg3.data_ptr(), None, k_out, None,
+                                    27, cin, cout, None, None, 0, y.data_ptr(), 0, 0, st) == -1

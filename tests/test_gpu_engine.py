@@ -192,6 +192,32 @@ def test_engine_bf16x8_is_fp32_grade(cuda):
             assert torch.equal(eng.forward(c), out)
 
 
+@pytest.mark.parametrize("mode", ["auto", "all"])
+def test_engine_bf16x6_is_fp32_grade(cuda, mode, monkeypatch):
+    """conv_math="bf16x6": rows travel between the chosen layers as three exact bf16 planes
+    (lcf_split_planes at the entry, lcf_indice_conv_fwd_x6 writing planes or fp32 rows); the
+    network's output stays at fp32 reassociation distance from the fp32 module path, frames of
+    other sizes through the same graph included, run to run bit-identical.  "auto" = the layers
+    where the form measured ahead (32 -> 32 on this frame), "all" = every candidate layer."""
+    monkeypatch.setenv("LCF_ENGINE_X6", mode)
+    model = randomize_(SparseFrontEnd("M2").eval(), 0).to(cuda)
+    with torch.no_grad():
+        eng = model.engine(calib=_clouds(cuda, [0, 1], 20000), conv_math="bf16x6")
+        used = [l for l in eng.layers if l.use_x6]
+        assert used and all(not l.planned for l in used)
+        assert any(l.split_in for l in used) and any(not l.out_planes for l in used)
+        if mode == "all":
+            assert sum(1 for l in used if l.out_planes) >= 6
+        for seed, n in [(0, 20000), (7, 3000), (3, 24000)]:
+            c = torch.from_numpy(synth.vkitti_frame(seed, n)).to(cuda)
+            out = eng.forward(c).clone()
+            eng.check()
+            ref = model([c])
+            err = ((out - ref).abs().max() / ref.abs().max()).item()
+            assert err < 2e-6, err
+            assert torch.equal(eng.forward(c), out)
+
+
 def test_load_points_copies_and_counts_in_one_launch(cuda):
     """lcf_load_points: the rows land where dst points, the device-side counter gets n_total;
     what the float4 copy cannot do is refused (the engine then copies and fills separately)."""
