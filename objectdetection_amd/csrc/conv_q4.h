@@ -48,7 +48,8 @@ struct Q4Cfg {
 
 static size_t q4_lds_bytes(int COUT, int kvol, int nw)
 {
-    return (size_t)tc_plan_stride(kvol) * 4 + (size_t)nw * 33 * COUT * 4;
+    // plan record + the waves' output tiles + scale | shift of the epilogue
+    return (size_t)tc_plan_stride(kvol) * 4 + (size_t)nw * 33 * COUT * 4 + (size_t)2 * COUT * 4;
 }
 
 // sb-th block's channels of a group (or of two groups with the same W registers)
@@ -124,18 +125,38 @@ cv_q4_kernel(const float *__restrict__ feat, const float *__restrict__ wimg,
     const int kh = wave % KS;       // input channels [kh * CW, (kh + 1) * CW)
     float *ot = ot0 + wave * OTE;
 
+    // scale | shift of the epilogue travel to LDS with the set-up (read from global memory in the
+    // epilogue they were one more round trip at the end of every tile's life)
+    float *ssl = ot0 + NW * OTE; // [2][COUT]
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (plan) {
+        // the record's loads are in flight while the output tiles are cleared: one barrier
         const int4 *src = reinterpret_cast<const int4 *>(plan + (size_t)blockIdx.x * plan_stride);
         int4 *dst = reinterpret_cast<int4 *>(ent);
-        for (int e = tidw; e < plan_stride / 4; e += TT) dst[e] = src[e];
-        __syncthreads();
+        const int nv = plan_stride / 4; // <= 2 * TT at 27 offsets with >= 3 waves, else a loop
+        const int4 r0 = tidw < nv ? src[tidw] : make_int4(0, 0, 0, 0);
+        const int4 r1 = tidw + TT < nv ? src[tidw + TT] : make_int4(0, 0, 0, 0);
+        auto ss_at = [&](int e) -> float {
+            return e < COUT ? (scale ? scale[e] : 1.f) : (shift ? shift[e - COUT] : 0.f);
+        };
+        const float sv0 = tidw < 2 * COUT ? ss_at(tidw) : 0.f;             // (TT >= 64,
+        const float sv1 = tidw + TT < 2 * COUT ? ss_at(tidw + TT) : 0.f;    //  2 COUT <= 128)
+        for (int e = tidw; e < NW * OTE / 4; e += TT) reinterpret_cast<float4 *>(ot0)[e] = zero4;
+        if (tidw < nv) dst[tidw] = r0;
+        if (tidw + TT < nv) dst[tidw + TT] = r1;
+        for (int e = tidw + 2 * TT; e < nv; e += TT) dst[e] = src[e];
+        if (tidw < 2 * COUT) ssl[tidw] = sv0;
+        if (tidw + TT < 2 * COUT) ssl[tidw + TT] = sv1;
     } else {
         tc_build_steps<NW, TT>(nbr, row0, tr, kvol, k_out, reinterpret_cast<int *>(ot0), ent, cnt,
                                gbase, soff, nsteps_p, DUMP);
+        // (the neighbour tile is dead now)
+        for (int e = tidw; e < NW * OTE / 4; e += TT) reinterpret_cast<float4 *>(ot0)[e] = zero4;
+        for (int e = tidw; e < 2 * COUT; e += TT)
+            ssl[e] = e < COUT ? (scale ? scale[e] : 1.f) : (shift ? shift[e - COUT] : 0.f);
     }
-    for (int e = tidw; e < NW * OTE; e += TT) ot0[e] = 0.f; // (the neighbour tile is dead now)
-    const int n_steps = __builtin_amdgcn_readfirstlane(*nsteps_p);
     __syncthreads();
+    const int n_steps = __builtin_amdgcn_readfirstlane(*nsteps_p);
 
     // lane -> (row of the group, block = channel slot, output column)
     const int h = COUT == 64 ? 0 : (lane >> 5);     // row quad of the group (8-row groups)
@@ -303,11 +324,11 @@ cv_q4_kernel(const float *__restrict__ feat, const float *__restrict__ wimg,
                 v.x += v1.x; v.y += v1.y; v.z += v1.z; v.w += v1.w;
             }
             if (scale) {
-                const float4 s = *reinterpret_cast<const float4 *>(scale + c4 * 4);
+                const float4 s = *reinterpret_cast<const float4 *>(ssl + c4 * 4);
                 v.x *= s.x; v.y *= s.y; v.z *= s.z; v.w *= s.w;
             }
             if (shift) {
-                const float4 s = *reinterpret_cast<const float4 *>(shift + c4 * 4);
+                const float4 s = *reinterpret_cast<const float4 *>(ssl + COUT + c4 * 4);
                 v.x += s.x; v.y += s.y; v.z += s.z; v.w += s.w;
             }
             if (relu) {
