@@ -344,6 +344,13 @@ cv_ss_kernel(const float *__restrict__ feat, const float *__restrict__ wimg,
     const int wave = tid >> 6;
     const int r16 = lane & 15;
     const int q = lane >> 4;
+    // (scale | shift of the epilogue are requested with the table rows: a thread's column there is
+    // tid % COUT whatever the row, and read in the epilogue they were one more round trip at the
+    // end of every workgroup's life)
+    static_assert(CV_BLOCK % COUT == 0, "a thread keeps its column");
+    const int ecol = tid % COUT;
+    const float esc = (scale && ecol < cout) ? scale[ecol] : 1.f;
+    const float esh = (shift && ecol < cout) ? shift[ecol] : 0.f;
     {
         const long long gb = (long long)row0 * kvol, gl = (long long)k_out * kvol;
         for (int e = tid; e < 16 * kvol; e += CV_BLOCK) nl[e] = (gb + e < gl) ? nbr[gb + e] : -1;
@@ -492,8 +499,8 @@ cv_ss_kernel(const float *__restrict__ feat, const float *__restrict__ wimg,
         if (row < k_out && c < cout) {
             float v = ((red[e] + red[16 * COUT + e]) + red[2 * 16 * COUT + e]) +
                       red[3 * 16 * COUT + e];
-            if (scale) v *= scale[c];
-            if (shift) v += shift[c];
+            if (scale) v *= esc;
+            if (shift) v += esh;
             if (relu) v = fmaxf(v, 0.f);
             out[(size_t)row * cout + c] = v;
         }
