@@ -97,11 +97,16 @@ def dominant_kernel_roofline(model, clouds, math="f32", reps=20):
     avg_s = total_ms / n * 1e-3
     tflops = total_flops / n / avg_s / 1e12
     gbs = total_bytes / n / avg_s / 1e9
-    traffic = None  # HBM bytes per launch from the committed PMC passes (tools/pmc_summary.py)
+    # HBM bytes per launch: NOT measured in this run (PMC counters need rocprofv3 passes of their
+    # own) -- read from the committed summary of those passes and labelled so in the line
+    traffic, traffic_source = None, None
     if math == "f32":
         try:
             with open(os.path.join(ROOT, "profiles", "pmc_dominant_kernel.json")) as fh:
-                traffic = json.load(fh)["hbm_bytes_per_launch"]
+                rec = json.load(fh)
+            traffic = rec["hbm_bytes_per_launch"]
+            traffic_source = ("committed PMC passes (FETCH_SIZE / WRITE_SIZE, corrected as "
+                              "MI355X_MICROARCH.md prescribes): " + rec.get("source", "profiles/"))
         except (OSError, KeyError, ValueError):
             pass
     common = {"kernel": "cv_q4_kernel<64,64,4>" if math == "f32" else
@@ -117,7 +122,7 @@ def dominant_kernel_roofline(model, clouds, math="f32", reps=20):
         # bandwidth-bound; its own byte formula says otherwise); the HBM view is reported too
         return {"bound": "mfma", "achieved": round(tflops, 3), "peak": F32_MFMA_PEAK_TFLOPS,
                 "unit": "TFLOP/s", "frac": round(tflops / F32_MFMA_PEAK_TFLOPS, 4),
-                "traffic": traffic,
+                "traffic": traffic, "traffic_source": traffic_source,
                 "bound_rationale": "algorithmic intensity above the fp32 ridge (157.3 TFLOP/s / "
                                    "8 TB/s = 19.7 flop/B): MFMA-bound; fp32 MFMA and VALU share "
                                    "one datapath on gfx950 (DESIGN.md section 4)",
